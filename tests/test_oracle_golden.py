@@ -1,0 +1,228 @@
+"""Pins oracle/pir_oracle.py to the golden vectors captured from the reference (tools/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, state_from_npz, rel_err
+from oracle import pir_oracle as O
+
+TOL = 2e-5  # same torch CPU kernels on both sides; slack only for op-order differences
+
+
+def _sdf_cfg(d):
+    return dict(multires=int(d["cfg_multires"]), skip_in=tuple(int(v) for v in d["cfg_skip_in"]),
+                scale=float(d["cfg_scale"]))
+
+
+@pytest.mark.parametrize("name", ["sdf_small.npz", "sdf_small_bumpy.npz", "sdf_full.npz"])
+def test_sdf_forward_and_get_all(name):
+    d = load_golden(name)
+    st = state_from_npz(d)
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    layers = O.mlp_layers(params)
+    kw = _sdf_cfg(d)
+    x = torch.from_numpy(d["x"])
+    assert rel_err(O.sdf_forward(layers, x, **kw).detach(), d["forward"]) < TOL
+    y, f, n = O.sdf_get_all(layers, x.clone(), is_training=False, **kw)
+    assert rel_err(y, d["sdf"]) < TOL and rel_err(f, d["feature"]) < TOL and rel_err(n, d["normal"]) < TOL
+    xt = x.clone()
+    y, f, n = O.sdf_get_all(layers, xt, is_training=True, **kw)
+    loss = (y * torch.from_numpy(d["cs"])).sum() + (f * torch.from_numpy(d["cf"])).sum() + \
+        (n * torch.from_numpy(d["cn"])).sum()
+    loss.backward()
+    assert abs(loss.item() - float(d["loss"])) < 1e-4 * abs(float(d["loss"])) + 1e-5
+    assert rel_err(xt.grad, d["grad_x"]) < 1e-4
+    for k, p in params.items():
+        g = p.grad.numpy()
+        ref = d["g." + k]
+        if g.shape != ref.shape:
+            g = g[::8]
+        assert rel_err(g, ref) < 1e-4, k
+
+
+def test_camera_and_sphere():
+    d = load_golden("camera.npz")
+    cam = O.CameraRays(int(d["W"]), int(d["H"]), torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"]))
+    uv = cam.pixel_centers()
+    assert np.array_equal(uv.numpy(), d["uv"])
+    o, dd, nn = cam.rays(uv)
+    assert rel_err(o, d["ray_o"]) < 1e-6 and rel_err(dd, d["ray_d"]) < 1e-6 and rel_err(nn, d["ray_d_norm"]) < 1e-6
+    m, lo, hi = O.intersect_sphere(o.reshape(-1, 3), dd.reshape(-1, 3), 1.0)
+    assert np.array_equal(m.numpy(), d["mask"])
+    assert rel_err(lo, d["min_dis"]) < 1e-6 and rel_err(hi, d["max_dis"]) < 1e-6
+    assert rel_err(cam.light_pos(torch.from_numpy(d["offset"])), d["light_pos"]) < 1e-6
+
+
+@pytest.mark.parametrize("name,weights", [("trace_std64.npz", "sdf_full.npz"), ("trace_wide48.npz", "sdf_full.npz"),
+                                          ("trace_bumpy64.npz", "sdf_full_bumpy_weights.npz"),
+                                          ("trace_crop800.npz", "sdf_full_bumpy_weights.npz"),
+                                          ("trace_vis32.npz", "sdf_full_bumpy_weights.npz")])
+def test_tracer(name, weights):
+    d = load_golden(name)
+    layers = O.mlp_layers(state_from_npz(load_golden(weights)))
+    cam = O.CameraRays(int(d["W"]), int(d["H"]), torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"]))
+    tr = O.Tracer()
+    with torch.no_grad():
+        o, dd, _ = cam.rays(cam.pixel_centers())
+        o, dd = o.reshape(-1, 3), dd.reshape(-1, 3)
+        m, lo, hi = O.intersect_sphere(o, dd, 1.0)
+        sdf = lambda x: O.sdf_forward(layers, x)[..., 0]  # noqa
+        conv, unf, pts, val, acc = tr.sphere_trace(sdf, o, dd, lo, hi, m)
+    assert np.array_equal(conv.numpy(), d["st_convergent"]) and np.array_equal(unf.numpy(), d["st_unfinished"])
+    assert np.abs(pts.numpy() - d["st_points"]).max() < 1e-5 and np.abs(acc.numpy() - d["st_dis"]).max() < 1e-5
+    res = O.raytrace_camera(cam, layers, tr)
+    assert np.array_equal(res["convergent_mask"].numpy(), d["cam_mask"])
+    assert np.abs(res["depth"].numpy() - d["cam_depth"]).max() < 1e-5
+    assert np.abs(res["points"].numpy() - d["cam_points"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("n_samples", [128, 256])
+def test_visibility(n_samples):
+    d = load_golden("visibility.npz")
+    st = state_from_npz(load_golden("sdf_full_bumpy_weights.npz"))
+    params = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    layers = O.mlp_layers(params)
+    cam = O.CameraRays(32, 32, torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"]))
+    off = torch.tensor([[0.2, 0.1, 0.0]], requires_grad=True)
+    lp = cam.light_pos(off)
+    pts = torch.from_numpy(d["points"])
+    inv_s = torch.from_numpy(d["inv_s"])
+    vis = O.light_visibility(lp, pts, layers, inv_s, n_samples=n_samples, is_training=True)
+    assert rel_err(vis.detach(), d[f"vis{n_samples}"]) < TOL
+    (vis * torch.from_numpy(d[f"c{n_samples}"])).sum().backward()
+    assert rel_err(off.grad, d[f"grad_offset{n_samples}"]) < 1e-4
+    for k, p in params.items():
+        g = p.grad.numpy()
+        ref = d[f"g{n_samples}." + k]
+        if g.shape != ref.shape:
+            g = g[::8]
+        assert rel_err(g, ref) < 2e-4, k
+    if n_samples == 128:
+        v2 = O.light_visibility(torch.from_numpy(d["light_pos_side"]), pts, O.mlp_layers(st), inv_s, 128, False)
+        assert rel_err(v2, d["vis_side128"]) < TOL
+
+
+def _tables():
+    import os
+    from conftest import ROOT
+    return O.load_ggx_tables(os.path.join(ROOT, "pir_amd", "renderer", "ggx"))
+
+
+def test_ggx_golden_and_known_answers():
+    d = load_golden("ggx.npz")
+    tabs = _tables()
+    names = ("distance", "normal", "lightdir", "viewdir", "kd", "ks", "alpha")
+    for tag, edr in (("offset", True), ("coloc", True), ("noedr", False)):
+        leaves = {n: torch.from_numpy(d[n]).clone().requires_grad_(True) for n in names}
+        light = torch.tensor(float(d["light"]), requires_grad=True)
+        ld = leaves["viewdir"] if tag == "coloc" else leaves["lightdir"]
+        o = O.ggx_shade(light, leaves["distance"], leaves["normal"], ld, leaves["viewdir"], leaves["kd"], leaves["ks"],
+                        leaves["alpha"], tabs, direct_radiance=edr)
+        for k in ("diffuse_rgb", "specular_rgb", "rgb"):
+            assert rel_err(o[k].detach(), d[f"{tag}.{k}"]) < TOL, (tag, k)
+        (o["rgb"] * torch.from_numpy(d[f"{tag}.cw"])).sum().backward()
+        assert rel_err(light.grad, d[f"{tag}.g_light"]) < 1e-4
+        for n in names:
+            if tag == "coloc" and n == "lightdir":
+                continue
+            g = leaves[n].grad if leaves[n].grad is not None else torch.zeros_like(leaves[n])
+            assert rel_err(g, d[f"{tag}.g_{n}"]) < 1e-4, (tag, n)
+    o = O.ggx_shade(torch.from_numpy(d["rgblight.light"]), *[torch.from_numpy(d[n]) for n in names], tabs,
+                    direct_radiance=False)
+    assert rel_err(o["rgb"], d["rgblight.rgb"]) < TOL
+    # known answers from SURVEY.md Appendix A (captured from the reference)
+    one = lambda *v: torch.tensor([list(v)], dtype=torch.float32)  # noqa
+    nrm = one(0, 0, 1)
+    o = O.ggx_shade(torch.tensor(10.0), one(2.0), nrm, nrm, nrm, one(.5, .5, .5), one(.5, .5, .5), one(0.1), tabs)
+    assert abs(o["diffuse_rgb"][0, 0].item() - 0.4032129943) < 1e-6
+    assert abs(o["specular_rgb"][0, 0].item() - 0.3831406832) < 1e-6
+    l = torch.nn.functional.normalize(one(0.3, 0.1, 1.0), dim=-1)
+    v = torch.nn.functional.normalize(one(-0.2, 0.4, 1.0), dim=-1)
+    o = O.ggx_shade(torch.tensor(10.0), one(2.0), nrm, l, v, one(.5, .5, .5), one(.5, .5, .5), one(0.3), tabs)
+    assert abs(o["diffuse_rgb"][0, 0].item() - 0.3632915318) < 1e-6
+    assert abs(o["specular_rgb"][0, 0].item() - 0.0172253586) < 1e-7
+
+
+def test_reparam():
+    d = load_golden("reparam.npz")
+    s = torch.from_numpy(d["sdf"]).clone().requires_grad_(True)
+    out = O.reparam_points(torch.from_numpy(d["points"]), torch.from_numpy(d["grads"]), torch.from_numpy(d["dirs"]), s)
+    assert np.array_equal(out.detach().numpy(), d["out"])
+    (out * torch.from_numpy(d["cw"])).sum().backward()
+    assert rel_err(s.grad, d["g_sdf"]) < 1e-6
+
+
+MAT_CFG = dict(
+    diffuse_albedo_network=dict(multires=10, multires_view=4, mode="idr", squeeze_out=True, skip_in=[4]),
+    specular_albedo_network=dict(multires=6, multires_view=-1, mode="no_view_dir", squeeze_out=False,
+                                 output_bias=0.4, output_scale=0.1),
+    specular_roughness_network=dict(multires=6, multires_view=-1, mode="no_view_dir", squeeze_out=False,
+                                    output_bias=0.1, output_scale=0.1),
+)
+DINO_CFG = dict(multires=6, output_bias=0.0, output_scale=1.0)
+
+
+def mats_from(d, requires_grad=False):
+    mats, params = {}, {}
+    for nm, cfg in MAT_CFG.items():
+        st = state_from_npz(d, f"mat.{nm}.")
+        if requires_grad:
+            st = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+        params[nm] = st
+        mats[nm] = dict(layers=O.mlp_layers(st), cfg=cfg)
+    dino = dict(layers=O.mlp_layers(state_from_npz(d, "mat.dino_network.")), cfg=DINO_CFG)
+    return mats, dino, params
+
+
+def test_render_fn():
+    d = load_golden("render_fn.npz")
+    mats, _, _ = mats_from(d)
+    tabs = _tables()
+    t = lambda k: torch.from_numpy(d[k])  # noqa
+    light = torch.tensor(float(d["mat.point_light_network.light"]))
+    for tag, kw in (("coloc", {}), ("offset", dict(lightdir=t("offset.lightdir"), distance=t("offset.distance"))),
+                    ("warmup", dict(roughness_warmup=True))):
+        with torch.no_grad():
+            r = O.render_fn(t("interior_mask"), mats, tabs, t("ray_o"), t("ray_d"), t("points"), t("normals"),
+                            t("geo_f"), t("dino_f"), light, **kw)
+        for k in ("color", "diffuse_color", "specular_color", "diffuse_albedo", "specular_albedo",
+                  "specular_roughness", "normal", "specular_grads", "roughness_grads"):
+            assert rel_err(r[k], d[f"{tag}.{k}"]) < TOL, (tag, k)
+
+
+@pytest.mark.parametrize("tag", ["coloc", "offset"])
+def test_end_to_end_tile(tag):
+    d = load_golden("e2e_tile.npz")
+    rf = load_golden("render_fn.npz")
+    st = state_from_npz(load_golden("sdf_full_bumpy_weights.npz"))
+    sdf_params = {k: v.clone().requires_grad_(True) for k, v in st.items()}
+    layers = O.mlp_layers(sdf_params)
+    mats, dino, mat_params = mats_from(rf, requires_grad=True)
+    cam = O.CameraRays(32, 32, torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"]))
+    light = torch.tensor(135.0, requires_grad=True)
+    off = torch.tensor([[0.2, 0.1, 0.0]], requires_grad=True) if tag == "offset" else None
+    res = O.render_view(cam, layers, mats, dino, _tables(), light, light_offset=off,
+                        inv_s=torch.from_numpy(d["inv_s"]), is_training=True)
+    assert np.array_equal(res["convergent_mask"].numpy(), d[f"{tag}.mask"])
+    assert rel_err(res["color"].detach(), d[f"{tag}.color"]) < TOL
+    assert rel_err(res["normal"].detach(), d[f"{tag}.normal"]) < TOL
+    assert np.abs(res["depth"].numpy() - d[f"{tag}.depth"]).max() < 1e-5
+    loss = O.step_loss(res)
+    assert abs(loss.item() - float(d[f"{tag}.loss"])) < 1e-4 * abs(float(d[f"{tag}.loss"]))
+    loss.backward()
+    if tag == "offset":
+        assert rel_err(res["vis"].detach(), d["offset.vis"]) < TOL
+        assert rel_err(off.grad, d["offset.g_offset"]) < 2e-4
+    assert rel_err(light.grad, d[f"{tag}.g_light"]) < 1e-4
+    for k, p in sdf_params.items():
+        g, ref = p.grad.numpy(), d[f"{tag}.g.sdf.{k}"]
+        if g.shape != ref.shape:
+            g = g[::8]
+        assert rel_err(g, ref) < 3e-4, k
+    for nm, ps in mat_params.items():
+        for k, p in ps.items():
+            g = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+            ref = d[f"{tag}.g.{nm}.{k}"]
+            if g.shape != ref.shape:
+                g = g[::8]
+            assert rel_err(g, ref) < 3e-4, (nm, k)

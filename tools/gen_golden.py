@@ -1,0 +1,370 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the *reference* PIR modules on CPU and dumps
+small input/output fixtures into tests/golden/*.npz.
+
+Runs ONLY in the build container (needs /root/reference); the fixtures it
+writes are plain data and are what travels to the GPU box.  Recipe follows
+SURVEY.md Appendix B: stub the unused third-party imports of
+src/renderer/raytracer.py (kornia, cv2, icecream, turtle), make `.cuda()` an
+identity in this process, import src.network / src.renderer.*, and evaluate the
+text of render_surface.py lines 40-176 (render_fn / get_materials) in a
+namespace that supplies the globals those lines expect.
+
+Usage:  python tools/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+sys.dont_write_bytecode = True
+
+
+def _install_stubs():
+    for name in ("kornia", "cv2", "icecream", "turtle"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["icecream"].ic = lambda *a, **k: None
+    sys.modules["turtle"].update = None
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    nn.Module.cuda = lambda self, *a, **k: self
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def state_to_np(prefix, module):
+    return {f"{prefix}{k}": _np(v) for k, v in module.state_dict().items()}
+
+
+SDF_FULL = dict(d_in=3, d_out=257, d_hidden=256, n_layers=8, skip_in=[4], multires=6,
+                bias=0.5, scale=1.0, geometric_init=True, weight_norm=True)
+SDF_SMALL = dict(d_in=3, d_out=33, d_hidden=64, n_layers=8, skip_in=[4], multires=6,
+                 bias=0.5, scale=1.0, geometric_init=True, weight_norm=True)
+
+
+def perturb(net, seed, rel):
+    """Make the random-init sphere bumpy: weight_v += N(0, rel*std(weight_v))."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("weight_v"):
+                p.add_(torch.randn(p.shape, generator=g) * p.std() * rel)
+
+
+def standard_camera(Camera, W, H, focal_mul=2.0, roty=0.0, tz=3.0, shift=(0.0, 0.0)):
+    f = focal_mul * W
+    K = torch.tensor([[f, 0, W / 2 + shift[0], 0], [0, f, H / 2 + shift[1], 0], [0, 0, 1, 0], [0, 0, 0, 1]],
+                     dtype=torch.float32)
+    c, s = np.cos(roty), np.sin(roty)
+    R = torch.tensor([[c, 0, s], [0, 1, 0], [-s, 0, c]], dtype=torch.float32)
+    W2C = torch.eye(4)
+    W2C[:3, :3] = R
+    W2C[2, 3] = tz
+    return Camera(W, H, K, W2C)
+
+
+def grads_subsample(named_params):
+    out = {}
+    for n, p in named_params:
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        g = _np(g)
+        if g.ndim == 2 and g.shape[0] * g.shape[1] > 40000:
+            g = g[::8]
+        out[n] = g
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    args = ap.parse_args()
+    out_dir = os.path.abspath(args.out)
+    os.makedirs(out_dir, exist_ok=True)
+
+    _install_stubs()
+    sys.path.insert(0, args.ref)
+    from src.network import SDFNetwork, RenderingNetwork, PointLightNetwork, DINONetwork  # noqa
+    from src.renderer.renderer_ggx import GGXColocatedRenderer  # noqa
+    import src.renderer.raytracer as rt  # noqa
+
+    torch.set_num_threads(8)
+
+    # ------------------------------------------------------------------ SDF
+    def sdf_fixture(cfg, name, seed, bumpy=None):
+        torch.manual_seed(seed)
+        net = SDFNetwork(**cfg)
+        if bumpy:
+            perturb(net, 1, bumpy)
+        g = torch.Generator().manual_seed(100 + seed)
+        x = (torch.rand(256, 3, generator=g) * 2 - 1) * 0.9
+        x[:8] *= 3.0  # a few points outside the unit sphere (light-march samples start there)
+        fwd = net(x)
+        d_out = cfg["d_out"]
+        # inference get_all
+        y0, f0, n0 = net.get_all(x.clone(), is_training=False)
+        # training get_all + backward of a fixed random linear functional
+        cs = torch.randn(256, 1, generator=g)
+        cf = torch.randn(256, d_out - 1, generator=g) * 0.1
+        cn = torch.randn(256, 3, generator=g)
+        xt = x.clone()
+        y, f, n = net.get_all(xt, is_training=True)
+        loss = (y * cs).sum() + (f * cf).sum() + (n * cn).sum()
+        net.zero_grad()
+        loss.backward()
+        d = dict(x=_np(x), forward=_np(fwd), sdf=_np(y0), feature=_np(f0), normal=_np(n0),
+                 cs=_np(cs), cf=_np(cf), cn=_np(cn), loss=np.float64(loss.item()), grad_x=_np(xt.grad))
+        d.update({"cfg_" + k: np.asarray(v) for k, v in cfg.items()})
+        d.update(state_to_np("w.", net))
+        d.update({"g." + k: v for k, v in grads_subsample(net.named_parameters()).items()})
+        # sdf-only + normal-only functional (the visibility-march use: no feature grads)
+        xt2 = x.clone()
+        y2, _, n2 = net.get_all(xt2, is_training=True)
+        loss2 = (y2 * cs).sum() + (n2 * cn).sum()
+        net.zero_grad()
+        loss2.backward()
+        d["grad_x_nofeat"] = _np(xt2.grad)
+        d.update({"g2." + k: v for k, v in grads_subsample(net.named_parameters()).items()})
+        np.savez_compressed(os.path.join(out_dir, name), **d)
+        return net
+
+    sdf_fixture(SDF_SMALL, "sdf_small.npz", 0)
+    sdf_fixture(SDF_SMALL, "sdf_small_bumpy.npz", 3, bumpy=0.5)
+    net_full = sdf_fixture(SDF_FULL, "sdf_full.npz", 0)
+
+    # bumpy full-size network: same seed-0 init, perturbed weight_v (weights stored once more)
+    torch.manual_seed(0)
+    net_bumpy = SDFNetwork(**SDF_FULL)
+    perturb(net_bumpy, 1, 0.02)
+    np.savez_compressed(os.path.join(out_dir, "sdf_full_bumpy_weights.npz"), **state_to_np("w.", net_bumpy))
+
+    # --------------------------------------------------------------- camera
+    cam = standard_camera(rt.Camera, 40, 24, roty=0.3, shift=(3.0, -2.0))
+    uv = cam.get_uv()
+    ro, rd, rdn = cam.get_rays(uv)
+    m, dmin, dmax = rt.intersect_sphere(ro.view(-1, 3), rd.view(-1, 3), r=1.0)
+    off = torch.tensor([[0.2, 0.1, 0.0]])
+    np.savez_compressed(os.path.join(out_dir, "camera.npz"), K=_np(cam.K), W2C=_np(cam.W2C), W=40, H=24,
+                        uv=_np(uv), ray_o=_np(ro), ray_d=_np(rd), ray_d_norm=_np(rdn), mask=_np(m),
+                        min_dis=_np(dmin), max_dis=_np(dmax), offset=_np(off),
+                        light_pos=_np(cam.get_light_pos(off)))
+
+    # --------------------------------------------------------------- tracer
+    def trace_fixture(net, name, W, H, **camkw):
+        cam = standard_camera(rt.Camera, W, H, **camkw)
+        tracer = rt.RayTracer()
+        uv = cam.get_uv()
+        ray_o, ray_d, ray_d_norm = cam.get_rays(uv)
+        ray_o, ray_d = ray_o.reshape(-1, 3), ray_d.reshape(-1, 3)
+        sdf = lambda x: net(x)[..., 0]  # noqa
+        with torch.no_grad():
+            mask, dmin, dmax = rt.intersect_sphere(ray_o, ray_d, r=1.0)
+            st = tracer.sphere_tracing(sdf, ray_o, ray_d, dmin, dmax, mask)
+            full = tracer(sdf, ray_o, ray_d, dmin, dmax, mask)
+            res = rt.raytrace_camera(cam, net, tracer, fill_holes=False, detect_edges=False)
+        d = dict(K=_np(cam.K), W2C=_np(cam.W2C), W=W, H=H, work_mask=_np(mask), min_dis=_np(dmin), max_dis=_np(dmax),
+                 st_convergent=_np(st[0]), st_unfinished=_np(st[1]), st_points=_np(st[2]), st_sdf=_np(st[3]),
+                 st_dis=_np(st[4]),
+                 convergent_mask=_np(full["convergent_mask"]), points=_np(full["points"]), sdf=_np(full["sdf"]),
+                 distance=_np(full["distance"]), cam_depth=_np(res["depth"]), cam_mask=_np(res["convergent_mask"]),
+                 cam_points=_np(res["points"]))
+        np.savez_compressed(os.path.join(out_dir, name), **d)
+        return cam, res
+
+    trace_fixture(net_full, "trace_std64.npz", 64, 64)
+    trace_fixture(net_full, "trace_wide48.npz", 48, 48, focal_mul=1.0)
+    trace_fixture(net_bumpy, "trace_bumpy64.npz", 64, 64, roty=0.7)
+    # tile of an 800x800 view that straddles the silhouette (grazing rays -> sampler + bisection)
+    trace_fixture(net_bumpy, "trace_crop800.npz", 48, 48, focal_mul=2.0 * 800 / 48, shift=(-270.0 - 8.0, 0.0))
+
+    # ----------------------------------------------------------- visibility
+    cam, res = trace_fixture(net_bumpy, "trace_vis32.npz", 32, 32, roty=-0.4)
+    pts_all = res["points"][res["convergent_mask"]]
+    pts = pts_all[:: max(1, pts_all.shape[0] // 64)][:64].clone()
+    inv_s = torch.exp(torch.tensor(0.3) * 10.0).reshape(1, 1)
+    vis_d = dict(points=_np(pts), inv_s=_np(inv_s))
+    for n_samples in (128, 256):
+        offset = torch.tensor([[0.2, 0.1, 0.0]], requires_grad=True)
+        light_pos = cam.get_light_pos(offset)
+        net_bumpy.zero_grad()
+        vis = rt.light_visibility(light_pos, pts, net_bumpy, inv_s, n_samples=n_samples, is_training=True)
+        g = torch.Generator().manual_seed(7)
+        c = torch.rand(vis.shape, generator=g)
+        (vis * c).sum().backward()
+        vis_d[f"vis{n_samples}"] = _np(vis)
+        vis_d[f"c{n_samples}"] = _np(c)
+        vis_d[f"light_pos{n_samples}"] = _np(light_pos)
+        vis_d[f"grad_offset{n_samples}"] = _np(offset.grad)
+        vis_d.update({f"g{n_samples}." + k: v for k, v in grads_subsample(net_bumpy.named_parameters()).items()})
+        vis_nt = rt.light_visibility(light_pos.detach(), pts, net_bumpy, inv_s, n_samples=n_samples, is_training=False)
+        vis_d[f"vis_eval{n_samples}"] = _np(vis_nt)
+    # a light placed so that part of the object is self-shadowed (vis < 1 somewhere)
+    lp2 = torch.tensor([[2.5, 0.4, -1.2]])
+    vis_d["light_pos_side"] = _np(lp2)
+    vis_d["vis_side128"] = _np(rt.light_visibility(lp2, pts, net_bumpy, inv_s, n_samples=128, is_training=False))
+    vis_d["K"], vis_d["W2C"] = _np(cam.K), _np(cam.W2C)
+    np.savez_compressed(os.path.join(out_dir, "visibility.npz"), **vis_d)
+
+    # ------------------------------------------------------------------ GGX
+    ggx = GGXColocatedRenderer()
+    g = torch.Generator().manual_seed(11)
+    P = 4096
+    nrm = F.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    ldir = F.normalize(nrm + 0.8 * torch.randn(P, 3, generator=g), dim=-1)
+    vdir = F.normalize(nrm + 0.8 * torch.randn(P, 3, generator=g), dim=-1)
+    dist = torch.rand(P, 1, generator=g) * 3 + 0.5
+    kd = torch.rand(P, 3, generator=g)
+    ks = torch.rand(P, 3, generator=g)
+    alpha = torch.rand(P, 1, generator=g) * 0.8 + 0.01
+    # clamp-edge cases
+    ldir[:64] = nrm[:64]                # cos == 1 -> clamped high
+    vdir[32:96] = nrm[32:96]
+    ldir[96:128] = -nrm[96:128]         # cos < 0 -> clamped low
+    vdir[128:160] = -ldir[128:160]      # view + light == 0 -> half vector eps path
+    alpha[160:192] = 1e-5               # below the 1e-4 clamp
+    alpha[192:224] = 4.5                # above the table's alpha range
+    alpha[224:256] = 4.0
+    alpha[256:288] = 0.0
+    nrm[288:320] *= 1.7                 # un-normalised normal (the op itself does not normalise)
+    ggx_d = {}
+    for tag, ldir_case, edr in (("offset", ldir, True), ("coloc", vdir, True), ("noedr", ldir, False)):
+        leaves = [t.clone().requires_grad_(True) for t in (dist, nrm, ldir_case, vdir, kd, ks, alpha)]
+        light = torch.tensor(135.0, requires_grad=True)
+        if tag == "coloc":
+            o = ggx(light, leaves[0], leaves[1], leaves[3], leaves[3], leaves[4], leaves[5], leaves[6], EDirectRadiance=edr)
+        else:
+            o = ggx(light, *leaves, EDirectRadiance=edr)
+        cw = torch.rand(P, 3, generator=g)
+        (o["rgb"] * cw).sum().backward()
+        ggx_d.update({f"{tag}.diffuse_rgb": _np(o["diffuse_rgb"]), f"{tag}.specular_rgb": _np(o["specular_rgb"]),
+                      f"{tag}.rgb": _np(o["rgb"]), f"{tag}.cw": _np(cw), f"{tag}.g_light": _np(light.grad)})
+        for nm, t in zip(("distance", "normal", "lightdir", "viewdir", "kd", "ks", "alpha"), leaves):
+            ggx_d[f"{tag}.g_{nm}"] = _np(t.grad if t.grad is not None else torch.zeros_like(t))
+    ggx_d.update(distance=_np(dist), normal=_np(nrm), lightdir=_np(ldir), viewdir=_np(vdir), kd=_np(kd), ks=_np(ks),
+                 alpha=_np(alpha), light=np.float32(135.0))
+    # per-point RGB light (indirect path uses EDirectRadiance=False with [P,3] radiance)
+    lrgb = torch.rand(P, 3, generator=g)
+    o = ggx(lrgb, dist, nrm, ldir, vdir, kd, ks, alpha, EDirectRadiance=False)
+    ggx_d["rgblight.light"] = _np(lrgb)
+    ggx_d["rgblight.rgb"] = _np(o["rgb"])
+    np.savez_compressed(os.path.join(out_dir, "ggx.npz"), **ggx_d)
+
+    # --------------------------------------------------------------- reparam
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(128, 3, generator=g)
+    gr = F.normalize(torch.randn(128, 3, generator=g), dim=-1)
+    dr = F.normalize(gr + 0.7 * torch.randn(128, 3, generator=g), dim=-1)
+    dr[:16] = -dr[:16]  # negative dot -> clamp path
+    sv = torch.randn(128, 1, generator=g).requires_grad_(True)
+    rp = rt.reparam_points(p0, gr, dr, sv)
+    cw = torch.randn(128, 3, generator=g)
+    (rp * cw).sum().backward()
+    np.savez_compressed(os.path.join(out_dir, "reparam.npz"), points=_np(p0), grads=_np(gr), dirs=_np(dr), sdf=_np(sv),
+                        out=_np(rp), cw=_np(cw), g_sdf=_np(sv.grad))
+
+    # ------------------------------------------------- render_fn / materials
+    with open(os.path.join(args.ref, "render_surface.py")) as fh:
+        lines = fh.read().split("\n")
+    ns = dict(torch=torch, nn=nn, F=F, np=np, dino_dimension=384,
+              args=Namespace(is_metal=False, smoothness_weight=0.0), ggx_renderer_modified=ggx)
+    exec("\n".join(lines[39:176]), ns)
+    render_fn = ns["render_fn"]
+
+    MAT = dict(
+        diffuse_albedo_network=dict(d_in=9, d_out=3, d_feature=256, d_hidden=32, n_layers=8, multires=10,
+                                    multires_view=4, mode="idr", squeeze_out=True, skip_in=[4]),
+        specular_albedo_network=dict(d_in=262, d_out=3, d_feature=384, d_hidden=32, n_layers=4, multires=6,
+                                     multires_view=-1, mode="no_view_dir", squeeze_out=False, output_bias=0.4,
+                                     output_scale=0.1),
+        specular_roughness_network=dict(d_in=262, d_out=1, d_feature=384, d_hidden=32, n_layers=4, multires=6,
+                                        multires_view=-1, mode="no_view_dir", squeeze_out=False, output_bias=0.1,
+                                        output_scale=0.1),
+    )
+    DINO = dict(d_in=3, d_out=384, d_hidden=32, n_layers=4, skip_in=[], multires=6, output_bias=0.0, output_scale=1.0)
+    torch.manual_seed(21)
+    cnd = {k: RenderingNetwork(**v) for k, v in MAT.items()}
+    cnd["point_light_network"] = PointLightNetwork(enable_offset=True)
+    cnd["point_light_network"].set_light(135.0)
+    dino_net = DINONetwork(**DINO)
+    mat_state = {}
+    for k, v in cnd.items():
+        mat_state.update(state_to_np(f"mat.{k}.", v))
+    mat_state.update(state_to_np("mat.dino_network.", dino_net))
+
+    g = torch.Generator().manual_seed(31)
+    n_chunk = 96
+    imask = torch.rand(n_chunk, generator=g) > 0.4
+    Pm = int(imask.sum())
+    ro = torch.tensor([[0.0, 0.0, -3.0]]).expand(Pm, 3).contiguous()
+    ptsm = F.normalize(torch.randn(Pm, 3, generator=g), dim=-1) * 0.5
+    rdm = F.normalize(ptsm - ro, dim=-1)
+    nrmm = ptsm * 2.3 + 0.1 * torch.randn(Pm, 3, generator=g)
+    geo = torch.randn(Pm, 256, generator=g) * 0.3
+    dinof = torch.randn(Pm, 384, generator=g) * 0.3
+    rf_d = dict(interior_mask=_np(imask), ray_o=_np(ro), ray_d=_np(rdm), points=_np(ptsm), normals=_np(nrmm),
+                geo_f=_np(geo), dino_f=_np(dinof))
+    for tag, kw in (("coloc", {}),
+                    ("offset", dict(lightdir=F.normalize(ptsm - torch.tensor([[0.2, 0.1, -3.0]]), eps=1e-10),
+                                    distance=(ptsm - torch.tensor([[0.2, 0.1, -3.0]])).norm(dim=-1, keepdim=True))),
+                    ("warmup", dict(roughness_warmup=True))):
+        with torch.no_grad():
+            r = render_fn(imask, cnd, ro, rdm, ptsm, nrmm, geo, dinof, is_training=False, **kw)
+        rf_d.update({f"{tag}.{k}": _np(v) for k, v in r.items()})
+        if "lightdir" in kw:
+            rf_d["offset.lightdir"], rf_d["offset.distance"] = _np(kw["lightdir"]), _np(kw["distance"])
+    rf_d.update(mat_state)
+    np.savez_compressed(os.path.join(out_dir, "render_fn.npz"), **rf_d)
+
+    # ----------------------------------------------------- end-to-end 32x32
+    cam = standard_camera(rt.Camera, 32, 32, roty=0.25)
+    tracer = rt.RayTracer()
+    e2e = dict(K=_np(cam.K), W2C=_np(cam.W2C), W=32, H=32, inv_s=_np(inv_s))
+    for tag, use_vis in (("coloc", False), ("offset", True)):
+        for m_ in [net_bumpy, dino_net] + [v for v in cnd.values()]:
+            m_.zero_grad()
+        cnd["point_light_network"].light_offset.weight.data = torch.tensor([[0.2, 0.1, 0.0]])
+        results = rt.raytrace_camera(cam, net_bumpy, tracer, fill_holes=False, detect_edges=False)
+        results["edge_mask"] = torch.zeros_like(results["convergent_mask"])
+        light_pos = None
+        if use_vis:
+            light_pos = cam.get_light_pos(cnd["point_light_network"].offset)
+            rt.render_light_visibility(results, cam, light_pos, net_bumpy, inv_s, n_samples=128, max_num_pts=512,
+                                       is_training=True)
+        rt.render_normal_and_color(results, net_bumpy, cnd, dino_net, render_fn, is_training=True,
+                                   max_num_pts=320000, light_pos=light_pos)
+        color = results["color"]
+        if use_vis:
+            color = color * results["vis"][..., None]
+        nrm_img = results["normal"]
+        mask = results["convergent_mask"]
+        eik = ((nrm_img[mask].norm(dim=-1) - 1.0) ** 2).sum()
+        loss = color.sum() + eik
+        loss.backward()
+        e2e.update({f"{tag}.color": _np(results["color"]), f"{tag}.normal": _np(nrm_img), f"{tag}.mask": _np(mask),
+                    f"{tag}.depth": _np(results["depth"]), f"{tag}.loss": np.float64(loss.item()),
+                    f"{tag}.diffuse_albedo": _np(results["diffuse_albedo"]),
+                    f"{tag}.specular_roughness": _np(results["specular_roughness"])})
+        if use_vis:
+            e2e[f"{tag}.vis"] = _np(results["vis"])
+            e2e[f"{tag}.g_offset"] = _np(cnd["point_light_network"].light_offset.weight.grad)
+        e2e[f"{tag}.g_light"] = _np(cnd["point_light_network"].light.grad)
+        e2e.update({f"{tag}.g.sdf." + k: v for k, v in grads_subsample(net_bumpy.named_parameters()).items()})
+        for nm in MAT:
+            e2e.update({f"{tag}.g.{nm}." + k: v for k, v in grads_subsample(cnd[nm].named_parameters()).items()})
+    np.savez_compressed(os.path.join(out_dir, "e2e_tile.npz"), **e2e)
+
+    # known-answer GGX cases of SURVEY.md Appendix A are asserted directly in the tests.
+    tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+    print("wrote fixtures to", out_dir, "total bytes", tot)
+
+
+if __name__ == "__main__":
+    main()
