@@ -1,0 +1,71 @@
+"""ctypes binding of libpir_hip.so (the C ABI declared in include/pir_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `python -m pir_amd.build`.  There is no CPU or
+PyTorch fallback behind these calls: if the shared object is missing the import of any kernel raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpir_hip.so")
+_lib = None
+
+PIR_OK = 0
+_ERR = {1: "invalid argument", 2: "kernel launch failed", 3: "scratch buffer too small", 4: "size beyond the supported maximum"}
+
+
+class PirHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PirHipError(
+                f"{LIB_PATH} not found: build the HIP extension first (python -m pir_amd.build). "
+                "pir_amd has no fallback path for its kernels.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+def _declare(L):
+    vp, sz, lg, i32, f32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_long, ctypes.c_int, ctypes.c_float
+    L.pir_sdf_packed_bytes.restype = sz
+    L.pir_sdf_packed_bytes.argtypes = []
+    L.pir_sdf_scratch_bytes_per_workgroup.restype = sz
+    L.pir_sdf_scratch_bytes_per_workgroup.argtypes = []
+    L.pir_sdf_pack.restype = i32
+    L.pir_sdf_pack.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), vp, vp]
+    L.pir_sdf_forward.restype = i32
+    L.pir_sdf_forward.argtypes = [vp, vp, lg, vp, vp, vp]
+    L.pir_sdf_get_all.restype = i32
+    L.pir_sdf_get_all.argtypes = [vp, vp, lg, vp, vp, vp, vp, sz, vp]
+    for name, args in _OPTIONAL.items():
+        if hasattr(L, name):
+            fn = getattr(L, name)
+            fn.restype = i32
+            fn.argtypes = args
+
+
+_OPTIONAL = {}
+
+
+def check(code, what):
+    if code != PIR_OK:
+        raise PirHipError(f"{what}: {_ERR.get(code, 'error')} (code {code})")
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "pir_amd kernels take contiguous tensors"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

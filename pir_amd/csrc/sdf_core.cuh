@@ -1,0 +1,250 @@
+// SDF-MLP core for gfx950: a workgroup is a PAIR of wavefronts (128 threads) that pushes
+// two "operand sets" of 32 points each through the 8x256 softplus MLP of PIR's SDFNetwork
+// (reference: src/network.py:8-142) on the exact-f32 MFMA v_mfma_f32_32x32x2_f32.
+//
+// Orientation: activations are the B operand (k = feature, column = point), weights the A
+// operand (row = output neuron), so a layer's 32x32 accumulator tile has the point on the
+// lane and the neuron in the register -- exactly the B-operand shape of the next layer.
+// Activations live in LDS as [k-step][lane] images (one ds_read_b128 = 4 k-steps), weights
+// stream from L2 in a pre-packed fragment order (one global_load_dwordx4 = 4 k-steps).
+// Each wave owns 4 of the 8 output tiles for both sets: 128 accumulator registers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pir {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 128;      // 2 waves
+constexpr int kTilePts = 32;       // points per operand set
+constexpr int kSets = 2;           // operand sets per workgroup
+constexpr int kWgPts = 64;         // points per workgroup when both sets carry points
+constexpr int kTPW = 4;            // output tiles per wave
+constexpr int kActKB = 32;         // k-blocks (4 k-steps = 8 features) of the 256-feature region
+constexpr int kPeKB = 5;           // k-blocks of the positional-encoding region (20 slots x 2 halves)
+constexpr int kSetKB = kActKB + kPeKB;
+constexpr int kHidden = 256;
+constexpr int kSkipKeep = 217;     // outputs of lin3 (256 - 39)
+constexpr int kPeDim = 39;
+constexpr int kFeat = 256;         // feature outputs of lin8 (d_out - 1)
+
+// ---- packed weight stream ---------------------------------------------------------------
+// A product is stored as f32x4 [kb][tile][lane]; element c of the f32x4 is k-step 4*kb+c.
+// Offsets (in f32x4 units) into the one packed buffer, fixed by the architecture.
+constexpr int kTileKB = 64;  // f32x4 per (kb, tile)
+struct Prod { int off; int nkb; int ntiles; };
+constexpr int prod_size(int nkb, int ntiles) { return nkb * ntiles * kTileKB; }
+
+constexpr Prod kF0 = {0, kPeKB, 8};
+constexpr Prod kF1 = {kF0.off + prod_size(kF0.nkb, 8), kActKB, 8};
+constexpr Prod kF2 = {kF1.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kF3 = {kF2.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kF4 = {kF3.off + prod_size(kActKB, 8), kSetKB, 8};
+constexpr Prod kF5 = {kF4.off + prod_size(kSetKB, 8), kActKB, 8};
+constexpr Prod kF6 = {kF5.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kF7 = {kF6.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kF8 = {kF7.off + prod_size(kActKB, 8), kActKB, 8};       // feature rows 1..256 of lin8
+// transposed products (A = W^T): row = input feature of the layer, k = output neuron
+constexpr Prod kR8 = {kF8.off + prod_size(kActKB, 8), kActKB, 8};       // lin8 feature rows, transposed
+constexpr Prod kR7 = {kR8.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kR6 = {kR7.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kR5 = {kR6.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kR4 = {kR5.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kR4P = {kR4.off + prod_size(kActKB, 8), kActKB, 2};      // PE rows of lin4^T
+constexpr Prod kR3 = {kR4P.off + prod_size(kActKB, 2), kActKB, 8};
+constexpr Prod kR2 = {kR3.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kR1 = {kR2.off + prod_size(kActKB, 8), kActKB, 8};
+constexpr Prod kR0P = {kR1.off + prod_size(kActKB, 8), kActKB, 2};      // PE rows of lin0^T
+constexpr int kPackedF4 = kR0P.off + prod_size(kActKB, 2);              // total f32x4 count
+
+// vectors appended after the matrices (floats): bias[9][256], w8row[256]
+constexpr int kVecBias = 0;
+constexpr int kVecW8 = 9 * 256;
+constexpr int kVecB80 = 10 * 256;     // bias of the sdf output (lin8 row 0)
+constexpr int kVecFloats = 10 * 256 + 4;
+
+struct SdfPacked {
+  const f32x4* mats;   // kPackedF4 entries
+  const float* vecs;   // kVecFloats entries: bias of lin0..lin7, b8[1..256], w8 row 0, b8[0]
+};
+
+// ---- feature <-> (k-step, half) maps ---------------------------------------------------------
+// C/D layout of the 32x32 MFMA: lane = 32*h + point, register r holds tile row (r&3) + 8*(r>>2) + 4*h.
+__host__ __device__ constexpr int nat_feature(int s, int h) {
+  return 32 * (s >> 4) + ((s & 15) & 3) + 8 * ((s & 15) >> 2) + 4 * h;
+}
+// PE slots: slot 0 = (x0, x1), slot 1 = (x2, pad), slot 2+3k+c = (sin(2^k x_c), cos(2^k x_c)).
+// Returns the column of the 39-wide encoding (reference order, src/models/embedder.py:20-41) or -1.
+__host__ __device__ constexpr int pe_column(int slot, int h) {
+  if (slot == 0) return h;
+  if (slot == 1) return h == 0 ? 2 : -1;
+  if (slot >= 20) return -1;
+  int k = (slot - 2) / 3, c = (slot - 2) % 3;
+  return 3 + 6 * k + 3 * h + c;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- LDS image ------------------------------------------------------------------------------
+struct Lds {
+  f32x4 act[kSets][kSetKB][64];   // 2 x 37 KB
+  float red[2][kSets][kTilePts][4];  // cross-wave reductions (sdf, normal)
+};
+static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU must fit in 160 KB");
+
+// ---- the GEMM phase ---------------------------------------------------------------------------
+// acc[set][t] += W[tile 4*wave+t (or given first tile)] x act[set], over nkb k-blocks starting at LDS
+// k-block lds_kb0.  NT tiles for this wave starting at global tile `tile0`.
+template <int NT>
+__device__ __forceinline__ void mfma_block(const f32x4 (&w)[NT], const f32x4 (&b)[kSets], f32x16 (&acc)[kSets][NT]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][c], b[0][c], acc[0][t], 0, 0, 0);
+      acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][c], b[1][c], acc[1][t], 0, 0, 0);
+    }
+  }
+}
+
+// Software pipeline: the operands of k-block kb+1 (weights from L2, activations from LDS) are issued
+// before the 8*NT MFMAs of k-block kb; sched_barrier pins that order (hipcc otherwise sinks the loads
+// below the MFMAs and waits vmcnt(0) on them at once).
+template <int NT>
+__device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod p, int tile0, const Lds& lds,
+                                           int lds_kb0, f32x16 (&acc)[kSets][NT]) {
+  const int lane = lane_id();
+  const f32x4* w = mats + p.off + (size_t)tile0 * kTileKB + lane;
+  const int kb_stride = p.ntiles * kTileKB;
+  const int last = p.nkb - 1;
+  f32x4 wa[NT], wb[NT], ba[kSets], bb[kSets];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wa[t] = w[t * kTileKB];
+  ba[0] = lds.act[0][lds_kb0][lane];
+  ba[1] = lds.act[1][lds_kb0][lane];
+  int kb = 0;
+  for (; kb < last; kb += 2) {
+    {
+      const f32x4* wq = w + (size_t)(kb + 1) * kb_stride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wb[t] = wq[t * kTileKB];
+      bb[0] = lds.act[0][lds_kb0 + kb + 1][lane];
+      bb[1] = lds.act[1][lds_kb0 + kb + 1][lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NT>(wa, ba, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int k2 = kb + 2 <= last ? kb + 2 : last;
+      const f32x4* wq = w + (size_t)k2 * kb_stride;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) wa[t] = wq[t * kTileKB];
+      ba[0] = lds.act[0][lds_kb0 + k2][lane];
+      ba[1] = lds.act[1][lds_kb0 + k2][lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NT>(wb, bb, acc);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (kb == last) mfma_block<NT>(wa, ba, acc);
+}
+
+template <int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[kSets][NT]) {
+#pragma unroll
+  for (int s = 0; s < kSets; ++s)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[s][t][r] = 0.f;
+}
+
+// bias for tile T, register group g (registers 4g..4g+3) on lane half h: 4 consecutive features.
+__device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ v, int T, int g, int h) {
+  return *reinterpret_cast<const f32x4*>(v + 32 * T + 8 * g + 4 * h);
+}
+
+// softplus(beta=100, threshold=20) and its derivative sigma(100 z); reference: src/network.py:79.
+// t = exp(-|100 z|) via v_exp_f32; log via v_log_f32: absolute error of the activation ~1e-9.
+__device__ __forceinline__ float softplus100(float z) {
+  float u = 100.f * z;
+  float t = __expf(-fabsf(u));
+  float sp = fmaxf(z, 0.f) + 0.01f * __logf(1.f + t);
+  return u > 20.f ? z : sp;
+}
+// sigma(100 z) recovered from a = softplus100(z): 1 - exp(-100 a)  (exact identity; 1 in the linear branch)
+__device__ __forceinline__ float dsoftplus_from_act(float a) { return 1.f - __expf(-100.f * a); }
+
+// sin/cos with a 3-term Cody-Waite reduction by pi/2 and the Cephes single-precision kernels
+// (|error| ~1e-7 for |a| < ~1e4; PE arguments are at most 32 |x|).  Avoids the Payne-Hanek slow
+// path that sincosf() inlines 18 times into every kernel.
+__device__ __forceinline__ void sincos_pe(float a, float& sn, float& cs) {
+  const float n = rintf(a * 0.636619772367581343f);
+  float r = fmaf(n, -1.57079625129699707031e+00f, a);
+  r = fmaf(n, -7.54978941586159635335e-08f, r);
+  r = fmaf(n, -5.39030252995776476554e-15f, r);
+  const float r2 = r * r;
+  float ps = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+  ps = fmaf(ps * r2, r, r);
+  float pc = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+  pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)n;
+  const float s1 = (q & 1) ? pc : ps;
+  const float c1 = (q & 1) ? ps : pc;
+  sn = (q & 2) ? -s1 : s1;
+  cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// ---- positional encoding into the PE region of one set ------------------------------------------
+// Lane (point j, half h) of wave `w` fills set w.  x = the point of (set w, j).
+__device__ __forceinline__ void write_pe(Lds& lds, int set, float x0, float x1, float x2) {
+  const int lane = lane_id();
+  const int h = lane >> 5;
+  float v[20];
+  v[0] = h ? x1 : x0;
+  v[1] = h ? 0.f : x2;
+  const float xs[3] = {x0, x1, x2};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float sn, cs;
+      sincos_pe(xs[c] * (float)(1 << k), sn, cs);
+      v[2 + 3 * k + c] = h ? cs : sn;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kPeKB; ++q) {
+    f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+    lds.act[set][kActKB + q][lane] = o;
+  }
+}
+
+// Hidden-layer epilogue: a = softplus(acc + bias) -> LDS natural region of both sets.
+// Optionally also stores the activations to a private scratch image (float4 per lane, coalesced).
+template <bool STORE>
+__device__ __forceinline__ void epilogue_softplus(Lds& lds, f32x16 (&acc)[kSets][kTPW], const float* __restrict__ bias,
+                                                  f32x4* __restrict__ scratch /* [set][T][g][lane] */) {
+  const int lane = lane_id(), h = lane >> 5, w = wave_id();
+#pragma unroll
+  for (int t = 0; t < kTPW; ++t) {
+    const int T = kTPW * w + t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 b = load_feat4(bias, T, g, h);
+#pragma unroll
+      for (int s = 0; s < kSets; ++s) {
+        f32x4 a;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = softplus100(acc[s][t][4 * g + c] + b[c]);
+        lds.act[s][4 * T + g][lane] = a;
+        if (STORE) scratch[((s * 8 + T) * 4 + g) * 64 + lane] = a;
+      }
+    }
+  }
+}
+
+}  // namespace pir

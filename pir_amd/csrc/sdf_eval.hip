@@ -1,0 +1,215 @@
+// SDF network entry points: weight packing, forward (sdf [+feature]), get_all (sdf [+feature] + normal).
+// Reference: SDFNetwork.forward / sdf / get_all, src/network.py:81-142.
+#include "sdf_sweeps.cuh"
+#include "pir_common.h"
+
+namespace pir {
+
+// --------------------------------------------------------------------------------- packing
+struct PackDesc {
+  int off, nkb, ntiles;   // f32x4 offset, k-blocks, tiles
+  int src;                // layer index 0..8
+  int transposed;         // 0: A rows = output neurons; 1: A rows = input features (W^T)
+  int out_kind;           // 0 natural, 1 PE tile
+  int out_limit, out_off;
+  int in_kind;            // 0 natural, 1 PE only, 2 natural (128 k-steps) then PE
+  int in_limit, in_off, in_pe_off;
+  float scale;
+};
+
+struct PackArgs {
+  const float* w[9];
+  const float* b[9];
+  int rows[9], cols[9];
+  PackDesc d[19];
+};
+
+__global__ void pack_kernel(PackArgs a, float* __restrict__ mats, float* __restrict__ vecs) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long nmat = (long)kPackedF4 * 4;
+  if (idx < nmat) {
+    int p = 0;
+#pragma unroll 1
+    for (int i = 1; i < 19; ++i)
+      if (idx >= (long)a.d[i].off * 4) p = i;
+    const PackDesc d = a.d[p];
+    long e = idx - (long)d.off * 4;
+    const int c = e & 3; e >>= 2;
+    const int lane = e & 63; e >>= 6;
+    const int T = (int)(e % d.ntiles);
+    const int kb = (int)(e / d.ntiles);
+    const int i = lane & 31, h = lane >> 5, s = 4 * kb + c;
+    // output-side index (row of the A operand)
+    int oi = -1;
+    if (d.out_kind == 0) {
+      const int f = 32 * T + i;
+      if (f < d.out_limit) oi = f + d.out_off;
+    } else {
+      const int r = (i & 3) + 4 * (i >> 3), hh = (i >> 2) & 1;
+      const int col = pe_column(16 * T + r, hh);
+      if (col >= 0) oi = col + d.out_off;
+    }
+    // k-side index
+    int ki = -1;
+    if (d.in_kind == 0 || (d.in_kind == 2 && s < 128)) {
+      const int f = nat_feature(s, h);
+      if (f < d.in_limit) ki = f + d.in_off;
+    } else {
+      const int col = pe_column(d.in_kind == 2 ? s - 128 : s, h);
+      if (col >= 0) ki = col + d.in_pe_off;
+    }
+    float v = 0.f;
+    if (oi >= 0 && ki >= 0) {
+      const int row = d.transposed ? ki : oi, col = d.transposed ? oi : ki;
+      if (row < a.rows[d.src] && col < a.cols[d.src]) v = a.w[d.src][(long)row * a.cols[d.src] + col] * d.scale;
+    }
+    mats[idx] = v;
+  } else if (idx < nmat + kVecFloats) {
+    const int j = (int)(idx - nmat);
+    float v = 0.f;
+    if (j < 9 * 256) {
+      const int l = j >> 8, f = j & 255;
+      if (l < 8) { if (f < a.rows[l]) v = a.b[l][f]; }
+      else v = a.b[8][1 + f];
+    } else if (j < 10 * 256) {
+      v = a.w[8][j - 9 * 256];
+    } else if (j == 10 * 256) {
+      v = a.b[8][0];
+    }
+    vecs[j] = v;
+  }
+}
+
+// --------------------------------------------------------------------------------- evaluation
+enum { kWantFeat = 1, kWantNormal = 2 };
+
+template <int FLAGS>
+__global__ void __launch_bounds__(kThreads, 1)
+sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __restrict__ sdf, float* __restrict__ feat,
+                float* __restrict__ normal, f32x4* __restrict__ scratch_all) {
+  __shared__ Lds lds;
+  constexpr bool kNormal = (FLAGS & kWantNormal) != 0;
+  const int lane = lane_id(), w = wave_id(), j = lane & 31;
+  const long ntiles = (M + kWgPts - 1) / kWgPts;
+  f32x4* scratch = kNormal ? scratch_all + (size_t)blockIdx.x * kScratchWgF4 : nullptr;
+  for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long base = tile * kWgPts;
+    const long P = base + 32 * w + j;
+    float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+    if (P < M) { x0 = x[3 * P]; x1 = x[3 * P + 1]; x2 = x[3 * P + 2]; }
+    forward_hidden<kNormal>(lds, pk, x0, x1, x2, scratch);
+    sdf_head(lds, pk);
+    if (FLAGS & kWantFeat) feature_head(lds, pk, feat, base, M);
+    __syncthreads();
+    if (threadIdx.x < kWgPts) {
+      const long Q = base + threadIdx.x;
+      if (Q < M) sdf[Q] = read_sdf(lds, pk, threadIdx.x >> 5, threadIdx.x & 31);
+    }
+    if (kNormal) {
+      normal_reverse(lds, pk, scratch);
+      __syncthreads();
+      if (threadIdx.x < kWgPts) {
+        const long Q = base + threadIdx.x;
+        if (Q < M) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) normal[3 * Q + c] = read_normal(lds, threadIdx.x >> 5, threadIdx.x & 31, c);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static void fill_desc(PackArgs& a) {
+  const float is2 = 0.70710678118654752440f;
+  auto D = [&](int i, Prod p, int src, int tr, int ok, int ol, int oo, int ik, int il, int io, int ipo, float sc) {
+    a.d[i] = PackDesc{p.off, p.nkb, p.ntiles, src, tr, ok, ol, oo, ik, il, io, ipo, sc};
+  };
+  D(0, kF0, 0, 0, 0, 256, 0, 1, 0, 0, 0, 1.f);
+  D(1, kF1, 1, 0, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(2, kF2, 2, 0, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(3, kF3, 3, 0, 0, kSkipKeep, 0, 0, 256, 0, 0, 1.f);
+  D(4, kF4, 4, 0, 0, 256, 0, 2, kSkipKeep, 0, kSkipKeep, is2);
+  D(5, kF5, 5, 0, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(6, kF6, 6, 0, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(7, kF7, 7, 0, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(8, kF8, 8, 0, 0, 256, 1, 0, 256, 0, 0, 1.f);
+  D(9, kR8, 8, 1, 0, 256, 0, 0, 256, 1, 0, 1.f);
+  D(10, kR7, 7, 1, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(11, kR6, 6, 1, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(12, kR5, 5, 1, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(13, kR4, 4, 1, 0, kSkipKeep, 0, 0, 256, 0, 0, is2);
+  D(14, kR4P, 4, 1, 1, 0, kSkipKeep, 0, 256, 0, 0, is2);
+  D(15, kR3, 3, 1, 0, 256, 0, 0, kSkipKeep, 0, 0, 1.f);
+  D(16, kR2, 2, 1, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(17, kR1, 1, 1, 0, 256, 0, 0, 256, 0, 0, 1.f);
+  D(18, kR0P, 0, 1, 1, 0, 0, 0, 256, 0, 0, 1.f);
+}
+
+}  // namespace pir
+
+using namespace pir;
+
+extern "C" {
+
+size_t pir_sdf_packed_bytes(void) { return (size_t)kPackedF4 * 16 + (size_t)kVecFloats * 4; }
+size_t pir_sdf_scratch_bytes_per_workgroup(void) { return kScratchWgBytes; }
+
+int pir_sdf_pack(const float* const* w9, const float* const* b9, void* packed, void* stream) {
+  if (!w9 || !b9 || !packed) return PIR_ERR_ARG;
+  PackArgs a;
+  static const int rows[9] = {256, 256, 256, kSkipKeep, 256, 256, 256, 256, 257};
+  static const int cols[9] = {kPeDim, 256, 256, 256, 256, 256, 256, 256, 256};
+  for (int i = 0; i < 9; ++i) { a.w[i] = w9[i]; a.b[i] = b9[i]; a.rows[i] = rows[i]; a.cols[i] = cols[i]; }
+  fill_desc(a);
+  float* mats = (float*)packed;
+  float* vecs = mats + (size_t)kPackedF4 * 4;
+  const long n = (long)kPackedF4 * 4 + kVecFloats;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, mats, vecs);
+  return pir_check_launch();
+}
+
+static SdfPacked make_packed(const void* packed) {
+  SdfPacked pk;
+  pk.mats = (const f32x4*)packed;
+  pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
+  return pk;
+}
+
+int pir_sdf_forward(const void* packed, const float* x, long M, float* sdf, float* feat, void* stream) {
+  if (M < 0 || !packed || (M > 0 && (!x || !sdf))) return PIR_ERR_ARG;
+  if (M == 0) return PIR_OK;
+  SdfPacked pk = make_packed(packed);
+  const long ntiles = (M + kWgPts - 1) / kWgPts;
+  dim3 grid((unsigned)(ntiles < (1L << 30) ? ntiles : (1L << 30)));
+  if (feat)
+    hipLaunchKernelGGL(sdf_eval_kernel<kWantFeat>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf, feat,
+                       (float*)nullptr, (f32x4*)nullptr);
+  else
+    hipLaunchKernelGGL(sdf_eval_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf,
+                       (float*)nullptr, (float*)nullptr, (f32x4*)nullptr);
+  return pir_check_launch();
+}
+
+int pir_sdf_get_all(const void* packed, const float* x, long M, float* sdf, float* feat, float* normal, void* scratch,
+                    size_t scratch_bytes, void* stream) {
+  if (M < 0 || !packed || (M > 0 && (!x || !sdf || !normal || !scratch))) return PIR_ERR_ARG;
+  if (M == 0) return PIR_OK;
+  const long ntiles = (M + kWgPts - 1) / kWgPts;
+  long nwg = (long)(scratch_bytes / kScratchWgBytes);
+  if (nwg < 1) return PIR_ERR_SCRATCH;
+  const long resident = 2L * pir_num_cus();
+  if (nwg > resident) nwg = resident;
+  if (nwg > ntiles) nwg = ntiles;
+  SdfPacked pk = make_packed(packed);
+  dim3 grid((unsigned)nwg);
+  if (feat)
+    hipLaunchKernelGGL(sdf_eval_kernel<kWantFeat | kWantNormal>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x,
+                       M, sdf, feat, normal, (f32x4*)scratch);
+  else
+    hipLaunchKernelGGL(sdf_eval_kernel<kWantNormal>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf,
+                       (float*)nullptr, normal, (f32x4*)scratch);
+  return pir_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+"""Host side of the SDF-network kernels: packed weights, forward, get_all (value / feature / normal)."""
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+_SDF_SHAPES = [(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256), (256, 256), (257, 256)]
+_scratch_cache = {}
+
+
+def supported_architecture(shapes: Sequence[Tuple[int, int]]) -> bool:
+    return [tuple(s) for s in shapes] == _SDF_SHAPES
+
+
+def scratch_for(device, n_workgroups: Optional[int] = None) -> torch.Tensor:
+    """Per-device scratch for the resident workgroups of the get_all sweeps (2 per CU)."""
+    per = _lib.lib().pir_sdf_scratch_bytes_per_workgroup()
+    if n_workgroups is None:
+        n_workgroups = 2 * torch.cuda.get_device_properties(device).multi_processor_count
+    key = (torch.device(device).index, n_workgroups)
+    buf = _scratch_cache.get(key)
+    if buf is None:
+        buf = torch.empty(per * n_workgroups, dtype=torch.uint8, device=device)
+        _scratch_cache[key] = buf
+    return buf
+
+
+class PackedSdf:
+    """Weights of one SDFNetwork in MFMA fragment order (built once per optimisation step)."""
+
+    def __init__(self, weights: List[torch.Tensor], biases: List[torch.Tensor]):
+        L = _lib.lib()
+        assert len(weights) == 9 and len(biases) == 9
+        assert supported_architecture([w.shape for w in weights]), "unsupported SDF architecture for the HIP path"
+        dev = weights[0].device
+        assert dev.type == "cuda"
+        self._keep = [w.detach().contiguous().float() for w in weights] + [b.detach().contiguous().float() for b in biases]
+        self.device = dev
+        self.buf = torch.empty(L.pir_sdf_packed_bytes(), dtype=torch.uint8, device=dev)
+        wp = (ctypes.c_void_p * 9)(*[t.data_ptr() for t in self._keep[:9]])
+        bp = (ctypes.c_void_p * 9)(*[t.data_ptr() for t in self._keep[9:]])
+        with torch.cuda.device(dev):
+            _lib.check(L.pir_sdf_pack(wp, bp, _lib.ptr(self.buf), _lib.stream_ptr()), "pir_sdf_pack")
+
+    def forward(self, x: torch.Tensor, want_feature: bool = False):
+        x = x.detach().reshape(-1, 3).contiguous().float()
+        M = x.shape[0]
+        sdf = torch.empty(M, dtype=torch.float32, device=x.device)
+        feat = torch.empty(M, 256, dtype=torch.float32, device=x.device) if want_feature else None
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().pir_sdf_forward(_lib.ptr(self.buf), _lib.ptr(x), M, _lib.ptr(sdf), _lib.ptr(feat),
+                                                  _lib.stream_ptr()), "pir_sdf_forward")
+        return (sdf, feat) if want_feature else sdf
+
+    def get_all(self, x: torch.Tensor, want_feature: bool = True):
+        x = x.detach().reshape(-1, 3).contiguous().float()
+        M = x.shape[0]
+        sdf = torch.empty(M, dtype=torch.float32, device=x.device)
+        normal = torch.empty(M, 3, dtype=torch.float32, device=x.device)
+        feat = torch.empty(M, 256, dtype=torch.float32, device=x.device) if want_feature else None
+        scratch = scratch_for(x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().pir_sdf_get_all(_lib.ptr(self.buf), _lib.ptr(x), M, _lib.ptr(sdf), _lib.ptr(feat),
+                                                  _lib.ptr(normal), _lib.ptr(scratch), scratch.numel(),
+                                                  _lib.stream_ptr()), "pir_sdf_get_all")
+        return sdf, feat, normal
