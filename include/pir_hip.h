@@ -42,6 +42,61 @@ int pir_sdf_forward(const void* packed, const float* x, long M, float* sdf, floa
 int pir_sdf_get_all(const void* packed, const float* x, long M, float* sdf, float* feat, float* normal,
                     void* scratch, size_t scratch_bytes, void* stream);
 
+/* Scratch bytes for pir_sdf_get_all_backward when it processes chunk_points points per pass (fixed split-K
+ * slabs + 33 KB per point of stored operands). */
+size_t pir_sdf_backward_scratch_bytes(long chunk_points);
+
+/* Backward of SDFNetwork.get_all(x, is_training=True) (src/network.py:125-142 under autograd, incl. the double
+ * backward through the normal): given dL/dsdf [M], dL/dfeat [M,256], dL/dnormal [M,3] (each may be NULL = zero)
+ * accumulates (+=) dL/dW_l into gw9[l] (row-major [out_l,in_l], effective weights) and dL/db_l into gb9[l], and
+ * writes dL/dx into g_x [M,3] if non-NULL.  gw9/gb9 are HOST arrays of 9 device pointers, zero-initialised by the
+ * caller.  Processes the points in chunks sized by scratch_bytes; deterministic (no float atomics). */
+int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const float* g_sdf, const float* g_feat,
+                             const float* g_normal, float* g_x, float* const* gw9, float* const* gb9, void* scratch,
+                             size_t scratch_bytes, void* stream);
+
+/* ---- sphere tracer (src/renderer/raytracer.py:28-250, RayTracer) ----------------------------------- */
+
+/* Workspace bytes for pir_trace on n_rays rays. chunk = the reference's max_num_rays split (bisection rounds
+ * are shared by the rays of one chunk, raytracer.py:234); chunk <= 0 means one chunk. */
+size_t pir_trace_workspace_bytes(long n_rays, long chunk, int max_bisect);
+
+/* RayTracer.forward(sdf, ray_o, ray_d, min_dis, max_dis, work_mask) (raytracer.py:56-124) with sdf = the packed
+ * network: sphere tracing (<= sphere_tracing_iters steps), dense sampler (n_steps samples) and bisection.
+ * ray_o/ray_d [n,3], min_dis/max_dis [n], work_mask uint8[n] -> convergent uint8[n], points [n,3], sdf [n],
+ * distance [n].  max_bisect bounds the bisection rounds that are enqueued (the reference loops until every
+ * bracket is below 2*threshold; 8 rounds for unit-sphere rays); pir_trace_status reports if the bound was hit. */
+int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
+              const float* max_dis, const unsigned char* work_mask, float sdf_threshold, int sphere_tracing_iters,
+              int n_steps, long chunk, int max_bisect, unsigned char* convergent, float* points, float* sdf,
+              float* distance, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Synchronising read-back of the tracer status word (*host_status: 0 ok, 1 bisection bound hit). */
+int pir_trace_status(const void* workspace, int* host_status, void* stream);
+
+/* Camera.get_rays + intersect_sphere (raytracer.py:305-326, :253-273).  uv [n,2] or NULL for the pixel
+ * centres of a width-wide image; cam21 = K_inv[:3,:3] (9) | C2W[:3,:3] (9) | C2W[:3,3] (3). */
+int pir_camera_rays(long n, int width, const float* uv, const float* cam21, float radius, float* ray_o, float* ray_d,
+                    float* ray_d_norm, unsigned char* hit, float* min_dis, float* max_dis, void* stream);
+
+/* ---- GGX point-light shader (src/renderer/renderer_ggx.py:39-127, GGXColocatedRenderer.forward) ------ */
+
+/* light: device scalar, or [P,3] radiance when light_is_rgb; direct_radiance = EDirectRadiance. */
+int pir_ggx_forward(long P, const float* light, int light_is_rgb, int direct_radiance, const float* distance,
+                    const float* normal, const float* lightdir, const float* viewdir, const float* kd, const float* ks,
+                    const float* alpha, const float* table_rough, int n_rough, const float* table_diff, int n_diff,
+                    float* out_diffuse, float* out_specular, float* out_rgb, void* stream);
+
+/* Analytic backward. grad_diffuse / grad_specular: total gradients reaching diffuse_rgb and specular_rgb
+ * (the gradient of `rgb` is added to both by the caller).  g_light: per-point contributions, [P] (scalar
+ * light; sum them) or [P,3]. */
+int pir_ggx_backward(long P, const float* light, int light_is_rgb, int direct_radiance, const float* distance,
+                     const float* normal, const float* lightdir, const float* viewdir, const float* kd, const float* ks,
+                     const float* alpha, const float* table_rough, int n_rough, const float* table_diff, int n_diff,
+                     const float* grad_diffuse, const float* grad_specular, float* g_light, float* g_distance,
+                     float* g_normal, float* g_lightdir, float* g_viewdir, float* g_kd, float* g_ks, float* g_alpha,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,22 @@ def _declare(L):
     L.pir_sdf_forward.argtypes = [vp, vp, lg, vp, vp, vp]
     L.pir_sdf_get_all.restype = i32
     L.pir_sdf_get_all.argtypes = [vp, vp, lg, vp, vp, vp, vp, sz, vp]
+    L.pir_sdf_backward_scratch_bytes.restype = sz
+    L.pir_sdf_backward_scratch_bytes.argtypes = [lg]
+    L.pir_sdf_get_all_backward.restype = i32
+    L.pir_sdf_get_all_backward.argtypes = [vp, vp, lg, vp, vp, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, sz, vp]
+    L.pir_trace_workspace_bytes.restype = sz
+    L.pir_trace_workspace_bytes.argtypes = [lg, lg, i32]
+    L.pir_trace.restype = i32
+    L.pir_trace.argtypes = [vp, lg, vp, vp, vp, vp, vp, f32, i32, i32, lg, i32, vp, vp, vp, vp, vp, sz, vp]
+    L.pir_trace_status.restype = i32
+    L.pir_trace_status.argtypes = [vp, ctypes.POINTER(i32), vp]
+    L.pir_camera_rays.restype = i32
+    L.pir_camera_rays.argtypes = [lg, i32, vp, vp, f32, vp, vp, vp, vp, vp, vp, vp]
+    L.pir_ggx_forward.restype = i32
+    L.pir_ggx_forward.argtypes = [lg, vp, i32, i32] + [vp] * 8 + [i32, vp, i32, vp, vp, vp, vp]
+    L.pir_ggx_backward.restype = i32
+    L.pir_ggx_backward.argtypes = [lg, vp, i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 10 + [vp]
     for name, args in _OPTIONAL.items():
         if hasattr(L, name):
             fn = getattr(L, name)

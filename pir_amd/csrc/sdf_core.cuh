@@ -98,13 +98,13 @@ static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU must fit in 160 K
 // ---- the GEMM phase ---------------------------------------------------------------------------
 // acc[set][t] += W[tile 4*wave+t (or given first tile)] x act[set], over nkb k-blocks starting at LDS
 // k-block lds_kb0.  NT tiles for this wave starting at global tile `tile0`.
-template <int NT>
+template <int NT, bool ONLY1 = false>
 __device__ __forceinline__ void mfma_block(const f32x4 (&w)[NT], const f32x4 (&b)[kSets], f32x16 (&acc)[kSets][NT]) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][c], b[0][c], acc[0][t], 0, 0, 0);
+      if (!ONLY1) acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][c], b[0][c], acc[0][t], 0, 0, 0);
       acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[t][c], b[1][c], acc[1][t], 0, 0, 0);
     }
   }
@@ -113,7 +113,8 @@ __device__ __forceinline__ void mfma_block(const f32x4 (&w)[NT], const f32x4 (&b
 // Software pipeline: the operands of k-block kb+1 (weights from L2, activations from LDS) are issued
 // before the 8*NT MFMAs of k-block kb; sched_barrier pins that order (hipcc otherwise sinks the loads
 // below the MFMAs and waits vmcnt(0) on them at once).
-template <int NT>
+// ONLY1: multiply operand set 1 only (set 0's accumulators are left untouched).
+template <int NT, bool ONLY1 = false>
 __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod p, int tile0, const Lds& lds,
                                            int lds_kb0, f32x16 (&acc)[kSets][NT]) {
   const int lane = lane_id();
@@ -126,6 +127,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod 
   ba[0] = lds.act[0][lds_kb0][lane];
   ba[1] = lds.act[1][lds_kb0][lane];
   int kb = 0;
+#pragma nounroll
   for (; kb < last; kb += 2) {
     {
       const f32x4* wq = w + (size_t)(kb + 1) * kb_stride;
@@ -135,7 +137,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod 
       bb[1] = lds.act[1][lds_kb0 + kb + 1][lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfma_block<NT>(wa, ba, acc);
+    mfma_block<NT, ONLY1>(wa, ba, acc);
     __builtin_amdgcn_sched_barrier(0);
     {
       const int k2 = kb + 2 <= last ? kb + 2 : last;
@@ -146,10 +148,10 @@ __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod 
       ba[1] = lds.act[1][lds_kb0 + k2][lane];
     }
     __builtin_amdgcn_sched_barrier(0);
-    mfma_block<NT>(wb, bb, acc);
+    mfma_block<NT, ONLY1>(wb, bb, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (kb == last) mfma_block<NT>(wa, ba, acc);
+  if (kb == last) mfma_block<NT, ONLY1>(wa, ba, acc);
 }
 
 template <int NT>

@@ -1,0 +1,254 @@
+// Weight-gradient GEMM of the SDF backward:  dW_l += Zb_l H_l^T + Q_l Pb_l^T  (see sdf_backward.hip), a
+// [out x points] x [points x in] product with the reduction over the points of a chunk.  Split-K over
+// workgroups into fp32 slabs, then a deterministic slab reduction that accumulates into the caller's
+// gradient buffers (no float atomics: bitwise reproducible gradients).
+#include <hip/hip_runtime.h>
+#include "sdf_core.cuh"
+#include "sdf_backward.h"
+#include "pir_common.h"
+
+namespace pir {
+
+constexpr int kWgThreads = 256;
+constexpr int kWgTile = 128;     // C tile edge
+constexpr int kWgKPts = 32;      // points per K step staged in LDS
+constexpr int kMaxJobs = 40;
+constexpr int kKSplit = 16;
+
+struct WgJob {
+  const float* X1; const float* Y1;   // product 1 (Zb, H)
+  const float* X2; const float* Y2;   // product 2 (Q, Pb) or null
+  int ldy;                            // 256, or 64 for the encoding arrays
+  int x1_rows;                        // rows of X1 that exist (caller-owned g_feat is not padded); <0: all
+  int o0, i0;                         // C tile origin
+  int layer, row_off, rows, cols;     // destination: gW[layer][(row_off + o) * cols + i], o < rows
+  float scale;
+  int bias;                           // 1: this job also produces column sums of X1 (i0 == 0 jobs)
+};
+struct WgJobs { WgJob j[kMaxJobs]; int n; };
+
+__device__ __forceinline__ void stage_tile(float (*dst)[kWgTile], const float* __restrict__ src, int ld, int col0,
+                                           int row0, int rows_valid) {
+  // 32 rows x 128 floats; thread t moves 4 float4
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * kWgThreads + threadIdx.x;
+    const int r = idx >> 5, c4 = idx & 31;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (col0 + 4 * c4 < ld && (rows_valid < 0 || row0 + r < rows_valid))
+      v = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + r) * ld + col0 + 4 * c4);
+    *reinterpret_cast<f32x4*>(&dst[r][4 * c4]) = v;
+  }
+}
+
+__global__ void __launch_bounds__(kWgThreads)
+wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, float* __restrict__ slabs, float* __restrict__ bias_slabs) {
+  __shared__ float Xs[kWgKPts][kWgTile];
+  __shared__ float Ys[kWgKPts][kWgTile];
+  const int job_id = blockIdx.x / kKSplit, ks = blockIdx.x % kKSplit;
+  const WgJob jb = jobs.j[job_id];
+  const int total_it = n_rows / kWgKPts;
+  const int it0 = (int)((long)ks * total_it / kKSplit), it1 = (int)((long)(ks + 1) * total_it / kKSplit);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wr = wv >> 1, wc = wv & 1, lo = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;
+  const int ncols_y = jb.ldy - jb.i0 < kWgTile ? jb.ldy - jb.i0 : kWgTile;
+  const bool wave_has_cols = 64 * wc < ncols_y;
+  for (int it = it0; it < it1; ++it) {
+    const int row0 = it * kWgKPts;
+#pragma unroll 1
+    for (int prod = 0; prod < 2; ++prod) {
+      const float* X = prod ? jb.X2 : jb.X1;
+      const float* Y = prod ? jb.Y2 : jb.Y1;
+      if (!X) continue;
+      __syncthreads();
+      stage_tile(Xs, X, 256, jb.o0, row0, prod ? -1 : jb.x1_rows);
+      stage_tile(Ys, Y, jb.ldy, jb.i0, row0, -1);
+      __syncthreads();
+      if (prod == 0 && jb.bias) {
+        const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bsum += Xs[16 * half + r][col];
+      }
+      if (wave_has_cols) {
+#pragma unroll
+        for (int s = 0; s < kWgKPts / 2; ++s) {
+          const float a0 = Xs[2 * s + kh][64 * wr + lo], a1 = Xs[2 * s + kh][64 * wr + 32 + lo];
+          const float b0 = Ys[2 * s + kh][64 * wc + lo], b1 = Ys[2 * s + kh][64 * wc + 32 + lo];
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* slab = slabs + ((size_t)ks * jobs.n + job_id) * kWgTile * kWgTile;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 64 * wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int col = 64 * wc + 32 * b + lo;
+        slab[row * kWgTile + col] = acc[a][b][r];
+      }
+  if (jb.bias) {
+    __syncthreads();
+    float* red = &Xs[0][0];
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 128)
+      bias_slabs[((size_t)ks * jobs.n + job_id) * kWgTile + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+  }
+}
+
+// row 0 of dW8 and db8[0]:  sum_pts (g_sdf a7 + a7-tangent),  sum_pts g_sdf   -> partial[block][257]
+constexpr int kRow0Blocks = 128;
+__global__ void __launch_bounds__(256)
+row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const float* __restrict__ g_sdf /* chunk-local or null */,
+            int chunk_n, float* __restrict__ partial) {
+  const int col = threadIdx.x;
+  const int r0 = (int)((long)blockIdx.x * chunk_n / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * chunk_n / gridDim.x);
+  float s = 0.f, sg = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const float g = g_sdf ? g_sdf[r] : 0.f;
+    s += g * A7[(size_t)r * 256 + col] + Ad7[(size_t)r * 256 + col];
+    sg += g;
+  }
+  partial[blockIdx.x * 257 + col] = s;
+  if (col == 0) partial[blockIdx.x * 257 + 256] = sg;
+}
+
+struct GradOut { float* w[9]; float* b[9]; };
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(WgJobs jobs, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
+                    const float* __restrict__ row0_partial, GradOut out) {
+  const int job_id = blockIdx.x;
+  if (job_id == jobs.n) {   // the row-0 block
+    for (int col = threadIdx.x; col < 257; col += 256) {
+      float s = 0.f;
+      for (int b = 0; b < kRow0Blocks; ++b) s += row0_partial[b * 257 + col];
+      if (col < 256) out.w[8][col] += s; else out.b[8][0] += s;
+    }
+    return;
+  }
+  const WgJob jb = jobs.j[job_id];
+  const size_t stride = (size_t)jobs.n * kWgTile * kWgTile;
+  const float* base = slabs + (size_t)job_id * kWgTile * kWgTile;
+  for (int e = threadIdx.x; e < kWgTile * kWgTile; e += 256) {
+    const int o = jb.o0 + e / kWgTile, i = jb.i0 + e % kWgTile;
+    if (o >= jb.rows || i >= jb.cols) continue;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < kKSplit; ++k) s += base[k * stride + e];
+    out.w[jb.layer][(size_t)(jb.row_off + o) * jb.cols + i] += jb.scale * s;
+  }
+  if (jb.bias && threadIdx.x < kWgTile) {
+    const int o = jb.o0 + threadIdx.x;
+    if (o < jb.rows) {
+      float s = 0.f;
+      for (int k = 0; k < kKSplit; ++k) s += bias_slabs[((size_t)k * jobs.n + job_id) * kWgTile + threadIdx.x];
+      out.b[jb.layer][jb.row_off + o] += s;
+    }
+  }
+}
+
+static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t kSlabBytes = (size_t)kKSplit * kMaxJobs * kWgTile * kWgTile * 4;
+constexpr size_t kBiasSlabBytes = (size_t)kKSplit * kMaxJobs * kWgTile * 4;
+constexpr size_t kRow0Bytes = (size_t)kRow0Blocks * 257 * 4;
+constexpr size_t kFixedBytes = ((kSlabBytes + 255) & ~(size_t)255) + ((kBiasSlabBytes + 255) & ~(size_t)255) +
+                               ((kRow0Bytes + 255) & ~(size_t)255);
+
+}  // namespace pir
+
+using namespace pir;
+
+extern "C" {
+
+size_t pir_sdf_backward_scratch_bytes(long chunk_points) {
+  const size_t rows = (size_t)((chunk_points + 31) / 32) * 32;
+  return kFixedBytes + rows * kBwdRowBytes + 256;
+}
+
+int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const float* g_sdf, const float* g_feat,
+                             const float* g_normal, float* g_x, float* const* gw9, float* const* gb9, void* scratch,
+                             size_t scratch_bytes, void* stream_) {
+  if (M < 0 || !packed || !gw9 || !gb9) return PIR_ERR_ARG;
+  if (M == 0) return PIR_OK;
+  if (!x || !scratch) return PIR_ERR_ARG;
+  if (scratch_bytes < kFixedBytes + 32 * (size_t)kBwdRowBytes + 256) return PIR_ERR_SCRATCH;
+  hipStream_t stream = (hipStream_t)stream_;
+  long cap = (long)((scratch_bytes - kFixedBytes - 256) / kBwdRowBytes) / 32 * 32;
+  if (cap > 262144) cap = 262144;
+  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  float* slabs = (float*)p; p += al256(kSlabBytes);
+  float* bias_slabs = (float*)p; p += al256(kBiasSlabBytes);
+  float* row0 = (float*)p; p += al256(kRow0Bytes);
+  BwdScratch sc;
+  float* f = (float*)p;
+  sc.layer_stride = (size_t)cap * 256;
+  sc.A_ = f; f += 8 * sc.layer_stride;
+  sc.Ad_ = f; f += 8 * sc.layer_stride;
+  sc.Zb_ = f; f += 8 * sc.layer_stride;
+  sc.Q_ = f; f += 8 * sc.layer_stride;
+  sc.E = f; f += cap * 64;
+  sc.Ed = f;
+  GradOut out;
+  for (int l = 0; l < 9; ++l) { out.w[l] = gw9[l]; out.b[l] = gb9[l]; if (!out.w[l] || !out.b[l]) return PIR_ERR_ARG; }
+  static const int rows[9] = {256, 256, 256, kSkipKeep, 256, 256, 256, 256, 257};
+  static const int cols[9] = {kPeDim, 256, 256, 256, 256, 256, 256, 256, 256};
+  for (long base = 0; base < M; base += cap) {
+    const int n = (int)(M - base < cap ? M - base : cap);
+    const int n_rows = (n + 31) / 32 * 32;
+    int rc = pir_internal_bwd_sweep(packed, x, g_sdf, g_feat, g_normal, base, n, &sc, g_x, stream_);
+    if (rc != PIR_OK) return rc;
+    WgJobs jobs;
+    jobs.n = 0;
+    for (int l = 0; l < 8; ++l) {
+      const int ni = l == 0 ? 1 : 2;
+      for (int ot = 0; ot < 2; ++ot)
+        for (int itl = 0; itl < ni; ++itl) {
+          WgJob& j = jobs.j[jobs.n++];
+          j.X1 = sc.Zb(l); j.X2 = sc.Q(l);
+          j.Y1 = l == 0 ? sc.E : sc.A(l - 1);
+          j.Y2 = l == 0 ? sc.Ed : sc.Ad(l - 1);
+          j.ldy = l == 0 ? 64 : 256;
+          j.x1_rows = -1;
+          j.o0 = 128 * ot; j.i0 = 128 * itl;
+          j.layer = l; j.row_off = 0; j.rows = rows[l]; j.cols = cols[l];
+          j.scale = l == 4 ? 0.70710678118654752440f : 1.0f;
+          j.bias = itl == 0;
+        }
+    }
+    if (g_feat) {
+      for (int ot = 0; ot < 2; ++ot)
+        for (int itl = 0; itl < 2; ++itl) {
+          WgJob& j = jobs.j[jobs.n++];
+          j.X1 = g_feat + (size_t)base * 256; j.X2 = nullptr; j.Y1 = sc.A(7); j.Y2 = nullptr;
+          j.ldy = 256; j.x1_rows = n; j.o0 = 128 * ot; j.i0 = 128 * itl;
+          j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.scale = 1.0f; j.bias = itl == 0;
+        }
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * kKSplit), dim3(kWgThreads), 0, stream, jobs, n_rows, slabs,
+                       bias_slabs);
+    hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
+                       g_sdf ? g_sdf + base : nullptr, n, row0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(jobs.n + 1), dim3(256), 0, stream, jobs, slabs, bias_slabs, row0, out);
+    rc = pir_check_launch();
+    if (rc != PIR_OK) return rc;
+  }
+  return PIR_OK;
+}
+
+}  // extern "C"

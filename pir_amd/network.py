@@ -1,0 +1,314 @@
+"""Drop-in counterparts of the reference's src/network.py modules.
+
+`SDFNetwork` keeps the reference constructor, methods (`forward/sdf/sdf_hidden_appearance/gradient/get_all`)
+and state-dict keys (`lin{l}.weight_g`, `lin{l}.weight_v`, `lin{l}.bias`, src/network.py:8-142).  On a CUDA
+(ROCm) device with the configs/model_config.json architecture every evaluation runs in the HIP kernels of
+libpir_hip.so (pir_amd/csrc); the eager PyTorch expression below is the definition used on CPU (host-logic
+tests) and for non-standard architectures.  The material / light / DINO-field modules are the PyTorch
+(rocBLAS) side of the path.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .models.embedder import get_embedder
+from . import sdf_autograd
+
+
+class WNLinear(nn.Module):
+    """Linear layer with old-style weight normalisation along dim 0 (parameters weight_g [out,1],
+    weight_v [out,in], bias [out]) -- the parameter set nn.utils.weight_norm(nn.Linear) exposes."""
+
+    def __init__(self, d_in, d_out, weight_norm=True):
+        super().__init__()
+        lin = nn.Linear(d_in, d_out)  # PyTorch's default init, then re-parameterise
+        self.weight_norm = weight_norm
+        self.bias = nn.Parameter(lin.bias.detach().clone())
+        if weight_norm:
+            w = lin.weight.detach()
+            self.weight_g = nn.Parameter(w.norm(dim=1, keepdim=True))
+            self.weight_v = nn.Parameter(w.clone())
+        else:
+            self.weight = nn.Parameter(lin.weight.detach().clone())
+
+    def set_weight(self, w):
+        """Re-initialise from a plain weight matrix (g = row norms, v = w)."""
+        with torch.no_grad():
+            if self.weight_norm:
+                self.weight_v.copy_(w)
+                self.weight_g.copy_(w.norm(dim=1, keepdim=True))
+            else:
+                self.weight.copy_(w)
+
+    def effective_weight(self):
+        if not self.weight_norm:
+            return self.weight
+        return torch._weight_norm(self.weight_v, self.weight_g, 0)
+
+    def forward(self, x):
+        return F.linear(x, self.effective_weight(), self.bias)
+
+
+class SDFNetwork(nn.Module):
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, bias=0.5, scale=1,
+                 geometric_init=True, weight_norm=True, inside_outside=False):
+        super().__init__()
+        dims = [d_in] + [d_hidden] * n_layers + [d_out]
+        self.embed_fn_fine = None
+        if multires > 0:
+            self.embed_fn_fine, dims[0] = get_embedder(multires, input_dims=d_in)
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        self.scale = scale
+        self.multires = multires
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = WNLinear(dims[l], out_dim, weight_norm)
+            if geometric_init:  # IDR geometric initialisation (src/network.py:46-72): a sphere of radius `bias`
+                w = torch.empty(out_dim, dims[l])
+                if l == self.num_layers - 2:
+                    mean = math.sqrt(math.pi) / math.sqrt(dims[l])
+                    nn.init.normal_(w, mean=-mean if inside_outside else mean, std=1e-4)
+                    nn.init.constant_(lin.bias, bias if inside_outside else -bias)
+                else:
+                    nn.init.constant_(lin.bias, 0.0)
+                    nn.init.normal_(w, 0.0, math.sqrt(2) / math.sqrt(out_dim))
+                    if multires > 0 and l == 0:
+                        w[:, 3:] = 0.0
+                    elif multires > 0 and l in self.skip_in:
+                        w[:, -(dims[0] - 3):] = 0.0
+                lin.set_weight(w)
+            setattr(self, "lin" + str(l), lin)
+        self.activation = nn.Softplus(beta=100)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ parameters for the kernels
+    def layers(self):
+        return [getattr(self, "lin" + str(l)) for l in range(self.num_layers - 1)]
+
+    def effective_weights(self):
+        return [lin.effective_weight() for lin in self.layers()], [lin.bias for lin in self.layers()]
+
+    def hip_supported(self):
+        from .sdf_hip import supported_architecture
+        p = next(self.parameters())
+        return (p.is_cuda and self.scale == 1 and self.skip_in == (4,) and self.multires == 6
+                and supported_architecture([tuple(l.effective_weight().shape) if not l.weight_norm else
+                                            tuple(l.weight_v.shape) for l in self.layers()]))
+
+    def packed(self):
+        """Packed weights for the HIP kernels, rebuilt whenever a parameter changed (optimizer step, load)."""
+        from .sdf_hip import PackedSdf
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed is None or key != self._packed_key:
+            with torch.no_grad():
+                ws, bs = self.effective_weights()
+                self._packed = PackedSdf(ws, bs)
+            self._packed_key = key
+        return self._packed
+
+    # ------------------------------------------------------------------ reference API
+    def _forward_torch(self, inputs):
+        inputs = inputs * self.scale
+        e = self.embed_fn_fine(inputs) if self.embed_fn_fine is not None else inputs
+        x = e
+        for l, lin in enumerate(self.layers()):
+            if l in self.skip_in:
+                x = torch.cat([x, e], -1) / np.sqrt(2)
+            x = lin(x)
+            if l < self.num_layers - 2:
+                x = self.activation(x)
+        return torch.cat([x[..., :1] / self.scale, x[..., 1:]], dim=-1)
+
+    def forward(self, inputs):
+        if self.hip_supported():
+            shp = inputs.shape[:-1]
+            needs_grad = torch.is_grad_enabled() and (inputs.requires_grad or any(p.requires_grad for p in self.parameters()))
+            if not needs_grad:
+                sdf, feat = self.packed().forward(inputs.reshape(-1, 3), want_feature=True)
+                return torch.cat([sdf[:, None], feat], dim=-1).reshape(*shp, -1)
+            sdf, feat = sdf_autograd.sdf_forward(self, inputs.reshape(-1, 3))
+            return torch.cat([sdf[:, None], feat], dim=-1).reshape(*shp, -1)
+        return self._forward_torch(inputs)
+
+    def sdf(self, x):
+        if self.hip_supported() and not (torch.is_grad_enabled() and (x.requires_grad or
+                                         any(p.requires_grad for p in self.parameters()))):
+            return self.packed().forward(x.reshape(-1, 3)).reshape(*x.shape[:-1], 1)
+        return self.forward(x)[..., :1]
+
+    def sdf_hidden_appearance(self, x):
+        return self.forward(x)
+
+    def gradient(self, x):
+        return self.get_all(x, is_training=True)[2]
+
+    def get_all(self, x, is_training=True):
+        if self.hip_supported():
+            x.requires_grad_(True)  # the reference marks its argument in place (src/network.py:127)
+            if not is_training:
+                sdf, feat, nrm = self.packed().get_all(x.reshape(-1, 3), want_feature=True)
+                return sdf[:, None], feat, nrm
+            sdf, feat, nrm = sdf_autograd.sdf_get_all(self, x.reshape(-1, 3), want_feature=True)
+            return sdf[:, None], feat, nrm
+        with torch.enable_grad():
+            x.requires_grad_(True)
+            out = self._forward_torch(x)
+            y, feature = out[..., :1], out[..., 1:]
+            (g,) = torch.autograd.grad(y, x, torch.ones_like(y), create_graph=is_training, retain_graph=is_training)
+        if not is_training:
+            return y.detach(), feature.detach(), g.detach()
+        return y, feature, g
+
+    def get_sdf_normal(self, x, is_training=True):
+        """sdf [M], normal [M,3] without the 256 features (the light-visibility march needs no features)."""
+        if self.hip_supported():
+            if not is_training:
+                sdf, _, nrm = self.packed().get_all(x.reshape(-1, 3), want_feature=False)
+                return sdf, nrm
+            sdf, _, nrm = sdf_autograd.sdf_get_all(self, x.reshape(-1, 3), want_feature=False)
+            return sdf, nrm
+        y, _, g = self.get_all(x, is_training)
+        return y[..., 0], g
+
+
+class RenderingNetwork(nn.Module):
+    """Material MLP (reference: src/network.py:146-267).  mode 'idr': [pts, view, normal, geo_f];
+    mode 'no_view_dir': [pts, normal, geo_f, semantic_f]."""
+
+    def __init__(self, mode, d_in, d_feature, d_out, d_hidden, n_layers, weight_norm=True, multires=0,
+                 multires_view=0, squeeze_out=True, squeeze_out_scale=1.0, output_bias=0.0, output_scale=1.0,
+                 skip_in=()):
+        super().__init__()
+        self.mode = mode
+        self.squeeze_out = squeeze_out
+        dims = [d_in + d_feature] + [d_hidden] * n_layers + [d_out]
+        self.embed_fn = self.embedview_fn = None
+        if multires > 0:
+            self.embed_fn, ch = get_embedder(multires)
+            dims[0] += ch - 3
+        if multires_view > 0:
+            self.embedview_fn, ch = get_embedder(multires_view)
+            dims[0] += ch - 3
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                dims[l] += dims[0]
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            setattr(self, "lin" + str(l), WNLinear(dims[l], out_dim, weight_norm))
+        self.output_bias, self.output_scale, self.squeeze_out_scale = output_bias, output_scale, squeeze_out_scale
+
+    def forward(self, points, normals, view_dirs, geo_f, semantic_f=None):
+        if self.embed_fn is not None and points is not None:
+            points = self.embed_fn(points)
+        if self.embedview_fn is not None:
+            view_dirs = self.embedview_fn(view_dirs)
+        if self.mode == "idr":
+            inp = torch.cat([points, view_dirs, normals, geo_f], dim=-1)
+        elif self.mode == "no_view_dir":
+            inp = torch.cat([points, normals, geo_f, semantic_f], dim=-1)
+        else:
+            raise ValueError(self.mode)
+        x = inp
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
+            x = getattr(self, "lin" + str(l))(x)
+            if l < self.num_layers - 2:
+                x = F.relu(x)
+        x = self.output_scale * (x + self.output_bias)
+        if self.squeeze_out:
+            x = self.squeeze_out_scale * torch.sigmoid(x)
+        return x
+
+    @torch.enable_grad()
+    def get_all(self, points, normals, view_dirs, geo_f, semantic_f=None, is_training=True):
+        semantic_f.requires_grad_(True)
+        y = self.forward(points, normals, view_dirs, geo_f, semantic_f)
+        (g,) = torch.autograd.grad(y, semantic_f, torch.ones_like(y), create_graph=is_training, retain_graph=is_training)
+        return (y, g) if is_training else (y.detach(), g.detach())
+
+
+class PointLightNetwork(nn.Module):
+    """Learnable light intensity + camera-frame offset (reference: src/network.py:270-292)."""
+
+    def __init__(self, enable_offset=False):
+        super().__init__()
+        self.light = nn.Parameter(torch.tensor(5.0))
+        if enable_offset:
+            self.light_offset = nn.Embedding(1, 3)
+            self.light_offset.weight.data = torch.zeros(1, 3)
+
+    def forward(self):
+        return self.light
+
+    @property
+    def offset(self):
+        w = self.light_offset.weight
+        return self.light_offset(torch.zeros(1, dtype=torch.long, device=w.device))
+
+    def set_light(self, light):
+        self.light.data.fill_(light)
+
+    def get_light(self):
+        return self.light.data.detach()
+
+    def get_offset(self):
+        return self.light_offset.weight.data.detach()
+
+
+class SingleVarianceNetwork(nn.Module):
+    """inv_s = exp(10 * variance) (reference: src/network.py:370-379)."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.variance = nn.Parameter(torch.tensor(init_val))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=self.variance.device) * torch.exp(self.variance * 10.0)
+
+
+class DINONetwork(nn.Module):
+    """3 -> 384 feature field (reference: src/network.py:382-486)."""
+
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(), multires=0, output_bias=0.0, output_scale=1.0,
+                 weight_norm=True):
+        super().__init__()
+        dims = [d_in] + [d_hidden] * n_layers + [d_out]
+        self.embed_fn = None
+        if multires > 0:
+            self.embed_fn, ch = get_embedder(multires)
+            dims[0] += ch - 3
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                dims[l] += dims[0]
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            setattr(self, "lin" + str(l), WNLinear(dims[l], out_dim, weight_norm))
+        self.output_bias, self.output_scale = output_bias, output_scale
+
+    def forward(self, points, normals=None, features=None, dino_feature_split=None, is_training=False):
+        if self.embed_fn is not None:
+            points = self.embed_fn(points)
+        if normals is not None:
+            parts = [points, normals, features] + ([dino_feature_split] if dino_feature_split is not None else [])
+            inp = torch.cat(parts, dim=-1)
+        else:
+            inp = points
+        x = inp
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
+            x = getattr(self, "lin" + str(l))(x)
+            if l < self.num_layers - 2:
+                x = F.relu(x)
+        x = self.output_scale * (x + self.output_bias)
+        return x if is_training else x.detach()

@@ -1,0 +1,437 @@
+"""Drop-in counterparts of the hot-path functions of the reference's src/renderer/raytracer.py.
+
+Same names, arguments and result dictionaries as the reference (cited per function); on a CUDA/ROCm device the
+work is done by the HIP kernels in libpir_hip.so:
+
+  RayTracer.forward / raytrace_pixels  -> pir_camera_rays + pir_trace (sphere tracing, sampler, bisection)
+  light_visibility                     -> pir_sdf_get_all (+ backward) for the 118/246 march samples per point
+  render_normal_and_color              -> pir_sdf_get_all (+ backward), pir_ggx_forward/backward via render_fn
+
+The per-image chunking arguments (max_num_rays, max_num_pts) are accepted for signature compatibility; the
+kernels stream over any number of rays, so they only keep their one semantic effect (bisection rounds are
+shared by the rays of one max_num_rays chunk, raytracer.py:234).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+
+VERBOSE_MODE = False
+dimension = 384
+
+
+def reparam_points(nondiff_points, nondiff_grads, nondiff_trgt_dirs, diff_sdf_vals):
+    """Value-identical to the input points; gradient -dir/clamp(grad.dir, 1e-4) * d sdf (raytracer.py:18-25)."""
+    dot = (nondiff_grads * nondiff_trgt_dirs).sum(dim=-1, keepdim=True).clamp(min=1e-4)
+    return nondiff_points - nondiff_trgt_dirs / dot * (diff_sdf_vals - diff_sdf_vals.detach())
+
+
+class SdfCallable:
+    """`sdf(x) -> [...]` closure that still exposes the network, so RayTracer can run natively on it.
+    (The reference builds `lambda x: sdf_network(x)[..., 0]`, raytracer.py:426, which hides the weights.)"""
+
+    def __init__(self, sdf_network):
+        self.sdf_network = sdf_network
+
+    def __call__(self, x):
+        return self.sdf_network.sdf(x)[..., 0]
+
+
+_trace_ws = {}
+
+
+def _workspace(device, nbytes):
+    key = torch.device(device).index
+    buf = _trace_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _trace_ws[key] = buf
+    return buf
+
+
+class RayTracer(nn.Module):
+    """Sphere tracing + dense sampling + bisection (raytracer.py:28-250)."""
+
+    def __init__(self, sdf_threshold=5.0e-5, sphere_tracing_iters=16, n_steps=128, max_num_pts=200000):
+        super().__init__()
+        self.sdf_threshold = sdf_threshold
+        self.sphere_tracing_iters = sphere_tracing_iters
+        self.n_steps = n_steps
+        self.max_num_pts = max_num_pts
+        self.max_bisect = 12   # bisection rounds enqueued by the HIP path (8 are needed for unit-sphere rays)
+
+    # ---------------------------------------------------------------- native path
+    def _trace_hip(self, net, ray_o, ray_d, min_dis, max_dis, work_mask, chunk):
+        shp = min_dis.shape
+        dev = ray_o.device
+        flat = lambda t, w: t.detach().reshape(-1, w).contiguous().float() if w else t.detach().reshape(-1).contiguous().float()  # noqa: E731
+        o, d = flat(ray_o, 3), flat(ray_d, 3)
+        lo, hi = flat(min_dis, 0), flat(max_dis, 0)
+        wm = work_mask.detach().reshape(-1).contiguous().to(torch.uint8)
+        n = lo.shape[0]
+        conv = torch.empty(n, dtype=torch.uint8, device=dev)
+        pts = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        sdf = torch.empty(n, dtype=torch.float32, device=dev)
+        dis = torch.empty(n, dtype=torch.float32, device=dev)
+        L = _lib.lib()
+        chunk = int(chunk) if chunk else 0
+        ws = _workspace(dev, L.pir_trace_workspace_bytes(n, chunk, self.max_bisect))
+        with torch.cuda.device(dev):
+            _lib.check(L.pir_trace(_lib.ptr(net.packed().buf), n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(lo), _lib.ptr(hi),
+                                   _lib.ptr(wm), float(self.sdf_threshold), int(self.sphere_tracing_iters),
+                                   int(self.n_steps), chunk, int(self.max_bisect), _lib.ptr(conv), _lib.ptr(pts),
+                                   _lib.ptr(sdf), _lib.ptr(dis), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
+                       "pir_trace")
+        return {"convergent_mask": conv.bool().reshape(shp), "points": pts.reshape(*shp, 3),
+                "sdf": sdf.reshape(shp), "distance": dis.reshape(shp)}
+
+    def trace_status(self, device):
+        """Synchronising check that the last native trace on `device` did not hit the bisection bound."""
+        ws = _trace_ws.get(torch.device(device).index)
+        if ws is None:
+            return 0
+        st = ctypes.c_int(0)
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().pir_trace_status(_lib.ptr(ws), ctypes.byref(st), _lib.stream_ptr()), "pir_trace_status")
+        return st.value
+
+    @torch.no_grad()
+    def forward(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, chunk=None):
+        net = getattr(sdf, "sdf_network", None)
+        if net is not None and ray_o.is_cuda and net.hip_supported():
+            return self._trace_hip(net, ray_o, ray_d, min_dis, max_dis, work_mask, chunk)
+        return self._trace_torch(sdf, ray_o, ray_d, min_dis, max_dis, work_mask)
+
+    # ---------------------------------------------------------------- generic path for opaque callables / CPU
+    def _trace_torch(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask):
+        conv, unf, pts, val, acc = self.sphere_tracing(sdf, ray_o, ray_d, min_dis, max_dis, work_mask)
+        if unf.any():
+            outside = val[unf] > 0.0
+            lo = torch.where(outside, acc[unf], min_dis[unf])
+            hi = torch.where(outside, max_dis[unf], acc[unf])
+            found, p, s, d = self.ray_sampler(sdf, ray_o[unf], ray_d[unf], lo, hi)
+            conv[unf], pts[unf], val[unf], acc[unf] = found, p, s, d
+        return {"convergent_mask": conv, "points": pts, "sdf": val, "distance": acc}
+
+    def sphere_tracing(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask):
+        """raytracer.py:126-170."""
+        active = work_mask.clone()
+        acc = min_dis.clone()
+        pts = ray_o + ray_d * acc.unsqueeze(-1)
+        val = sdf(pts)
+        for it in range(self.sphere_tracing_iters + 1):
+            active = active & (val.abs() > self.sdf_threshold) & (acc < max_dis)
+            if it == self.sphere_tracing_iters or not active.any():
+                break
+            step = val[active]
+            acc[active] = acc[active] + step
+            pts[active] = pts[active] + ray_d[active] * step.unsqueeze(-1)
+            val[active] = sdf(pts[active])
+        conv = work_mask & ~active & (val.abs() <= self.sdf_threshold) & (acc < max_dis)
+        return conv, active, pts, val, acc
+
+    def ray_sampler(self, sdf, ray_o, ray_d, min_dis, max_dis):
+        """raytracer.py:172-227."""
+        n = self.n_steps
+        t = torch.linspace(0, 1, steps=n, device=min_dis.device).float().view(1, n)
+        z = min_dis.unsqueeze(-1) + t * (max_dis - min_dis).unsqueeze(-1)
+        p = (ray_o.unsqueeze(-2) + ray_d.unsqueeze(-2) * z.unsqueeze(-1)).reshape(-1, 3)
+        vals = torch.cat([sdf(c) for c in torch.split(p, self.max_num_pts, dim=0)], dim=0).reshape(-1, n)
+        neg = vals < 0
+        first = torch.where(neg.any(-1), neg.float().argmax(-1), torch.full_like(neg[:, 0], n, dtype=torch.long))
+        found = (first >= 1) & (first < n)
+        out_p, out_s, out_d = torch.zeros_like(ray_d), torch.zeros_like(min_dis), torch.zeros_like(min_dis)
+        if found.any():
+            i = first[found].unsqueeze(-1)
+            zf, vf = z[found], vals[found]
+            pp, dd, ss = self.rootfind(sdf, vf.gather(-1, i - 1).squeeze(-1), vf.gather(-1, i).squeeze(-1),
+                                       zf.gather(-1, i - 1).squeeze(-1), zf.gather(-1, i).squeeze(-1),
+                                       ray_o[found], ray_d[found])
+            out_p[found], out_s[found], out_d[found] = pp, ss, dd
+        return found, out_p, out_s, out_d
+
+    def rootfind(self, sdf, f_low, f_high, d_low, d_high, ray_o, ray_d):
+        """raytracer.py:229-250 (every bracket keeps halving while any ray of the call still works)."""
+        work = (f_low > 0) & (f_high < 0)
+        d_mid = (d_low + d_high) / 2.0
+        while work.any():
+            f_mid = sdf(ray_o + ray_d * d_mid.unsqueeze(-1))
+            pos = f_mid > 0
+            d_low, f_low = torch.where(pos, d_mid, d_low), torch.where(pos, f_mid, f_low)
+            d_high, f_high = torch.where(pos, d_high, d_mid), torch.where(pos, f_high, f_mid)
+            d_mid = (d_low + d_high) / 2.0
+            work = work & ((d_high - d_low) > 2 * self.sdf_threshold)
+        p_mid = ray_o + ray_d * d_mid.unsqueeze(-1)
+        return p_mid, d_mid, sdf(p_mid)
+
+
+@torch.no_grad()
+def intersect_sphere(ray_o, ray_d, r):
+    """raytracer.py:253-273: (hit mask, entry distance clamped at 0, exit distance)."""
+    d1 = -torch.sum(ray_d * ray_o, dim=-1) / torch.sum(ray_d * ray_d, dim=-1)
+    p = ray_o + d1.unsqueeze(-1) * ray_d
+    tmp = r * r - torch.sum(p * p, dim=-1)
+    d2 = torch.sqrt(torch.clamp(tmp, min=0.0)) / torch.norm(ray_d, dim=-1)
+    return tmp > 0.0, torch.clamp(d1 - d2, min=0.0), d1 + d2
+
+
+class Camera(object):
+    """raytracer.py:276-402 (cv2-based `resize` of images is outside the hot path and not provided)."""
+
+    def __init__(self, W, H, K, W2C):
+        self.W, self.H = W, H
+        self.K, self.W2C = K, W2C
+        self.K_inv = torch.inverse(K)
+        self.C2W = torch.inverse(W2C)
+        self.device = self.K.device
+        self._cam21 = None
+
+    def get_fx(self):
+        return self.K[0, 0]
+
+    def get_image_size(self):
+        return self.H, self.W
+
+    def get_light_pos(self, offset):
+        return torch.matmul(offset, self.C2W[:3, :3].transpose(1, 0)) + self.C2W[:3, 3].unsqueeze(0)
+
+    def cam21(self):
+        if self._cam21 is None:
+            self._cam21 = torch.cat([self.K_inv[:3, :3].reshape(-1), self.C2W[:3, :3].reshape(-1),
+                                     self.C2W[:3, 3].reshape(-1)]).contiguous().float()
+        return self._cam21
+
+    def get_rays(self, uv):
+        dots_sh = list(uv.shape[:-1])
+        uv1 = torch.cat((uv.reshape(-1, 2), torch.ones_like(uv.reshape(-1, 2)[..., 0:1])), dim=-1)
+        ray_d = torch.matmul(torch.matmul(uv1, self.K_inv[:3, :3].transpose(1, 0)),
+                             self.C2W[:3, :3].transpose(1, 0)).reshape(dots_sh + [3])
+        ray_d_norm = ray_d.norm(dim=-1)
+        ray_d = ray_d / ray_d_norm.unsqueeze(-1)
+        ray_o = self.C2W[:3, 3].unsqueeze(0).expand(uv1.shape[0], -1).reshape(dots_sh + [3])
+        return ray_o, ray_d, ray_d_norm
+
+    def get_camera_origin(self, prefix_shape=None):
+        ray_o = self.C2W[:3, 3]
+        if prefix_shape is not None:
+            prefix_shape = list(prefix_shape)
+            ray_o = ray_o.view([1] * len(prefix_shape) + [3]).expand(prefix_shape + [3])
+        return ray_o
+
+    def get_uv(self):
+        v, u = torch.meshgrid(torch.arange(self.H, dtype=torch.float32, device=self.device),
+                              torch.arange(self.W, dtype=torch.float32, device=self.device), indexing="ij")
+        return torch.stack((u, v), dim=-1) + 0.5
+
+    def project(self, points):
+        dots_sh = list(points.shape[:-1])
+        p = points.reshape(-1, 3)
+        p = torch.cat([p, torch.ones_like(p[:, :1])], dim=1)
+        uv = torch.matmul(torch.matmul(p, self.W2C.transpose(1, 0)), self.K.transpose(1, 0))
+        return (uv[:, :2] / uv[:, 2:3]).view(dots_sh + [2])
+
+    def crop_region(self, trgt_W, trgt_H, center_crop=False, ul_corner=None, images=None):
+        K = self.K.clone()
+        if ul_corner is not None:
+            ul_col, ul_row = ul_corner
+        elif center_crop:
+            ul_col, ul_row = self.W // 2 - trgt_W // 2, self.H // 2 - trgt_H // 2
+        else:
+            ul_col = np.random.randint(0, self.W - trgt_W)
+            ul_row = np.random.randint(0, self.H - trgt_H)
+        K[0, 2] -= ul_col
+        K[1, 2] -= ul_row
+        cropped = {}
+        if images is not None:
+            for key, img in images.items():
+                assert img.shape[0] == self.H and img.shape[1] == self.W, f"image size for {key} does not match"
+                cropped[key] = img[ul_row:ul_row + trgt_H, ul_col:ul_col + trgt_W]
+        return Camera(trgt_W, trgt_H, K, self.W2C.clone()), cropped
+
+
+def _camera_rays_hip(camera, uv, is_pixel_grid):
+    dev = camera.device
+    n = uv.numel() // 2
+    ray_o = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ray_d = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    ray_n = torch.empty(n, dtype=torch.float32, device=dev)
+    hit = torch.empty(n, dtype=torch.uint8, device=dev)
+    lo = torch.empty(n, dtype=torch.float32, device=dev)
+    hi = torch.empty(n, dtype=torch.float32, device=dev)
+    uvp = None if is_pixel_grid else uv.detach().reshape(-1, 2).contiguous().float()
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pir_camera_rays(n, int(camera.W), _lib.ptr(uvp), _lib.ptr(camera.cam21()), 1.0,
+                                              _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(ray_n), _lib.ptr(hit),
+                                              _lib.ptr(lo), _lib.ptr(hi), _lib.stream_ptr()), "pir_camera_rays")
+    return ray_o, ray_d, ray_n, hit.bool(), lo, hi
+
+
+@torch.no_grad()
+def raytrace_pixels(sdf_network, raytracer, uv, camera, mask=None, max_num_rays=200000, _pixel_grid=False):
+    """raytracer.py:405-484 -> dict(convergent_mask, points, sdf, distance, depth, uv, ray_o, ray_d, ray_d_norm)."""
+    dots_sh = list(uv.shape[:-1])
+    native = uv.is_cuda and hasattr(sdf_network, "hip_supported") and sdf_network.hip_supported()
+    if native:
+        ray_o, ray_d, ray_n, hit, lo, hi = _camera_rays_hip(camera, uv, _pixel_grid)
+        work = hit if mask is None else hit & mask.reshape(-1)
+        res = raytracer(SdfCallable(sdf_network), ray_o, ray_d, lo, hi, work, chunk=max_num_rays)
+    else:
+        ray_o, ray_d, ray_n = camera.get_rays(uv)
+        ray_o, ray_d, ray_n = ray_o.reshape(-1, 3), ray_d.reshape(-1, 3), ray_n.reshape(-1)
+        m = torch.ones_like(ray_n, dtype=torch.bool) if mask is None else mask.reshape(-1)
+        sdf = lambda x: sdf_network(x)[..., 0]  # noqa: E731
+        parts = []
+        for s in range(0, ray_n.shape[0], max_num_rays):
+            sl = slice(s, s + max_num_rays)
+            hit, lo, hi = intersect_sphere(ray_o[sl], ray_d[sl], r=1.0)
+            parts.append(raytracer(sdf, ray_o[sl], ray_d[sl], lo, hi, hit & m[sl]))
+        res = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
+    res["depth"] = res["distance"] / ray_n
+    out = {}
+    for k, v in res.items():
+        out[k] = v.reshape(dots_sh + [3]) if v.dim() == 2 else v.reshape(dots_sh)
+    out.update({"uv": uv, "ray_o": ray_o.reshape(dots_sh + [3]), "ray_d": ray_d.reshape(dots_sh + [3]),
+                "ray_d_norm": ray_n.reshape(dots_sh)})
+    return out
+
+
+def _closing3x3(depth):
+    """3x3 morphological closing with a flat structuring element (dilate, then erode), borders ignored."""
+    x = depth[None, None]
+    x = F.max_pool2d(x, 3, stride=1, padding=1)
+    x = -F.max_pool2d(-x, 3, stride=1, padding=1)
+    return x[0, 0]
+
+
+@torch.no_grad()
+def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=False, detect_edges=False):
+    """raytracer.py:618-666.  fill_holes uses a kornia-free 3x3 closing (parity with kornia unpinned);
+    detect_edges (IRON edge sampling, raytracer.py:497-615) is not part of the accelerated path yet."""
+    results = raytrace_pixels(sdf_network, raytracer, camera.get_uv(), camera, max_num_rays=max_num_rays,
+                              _pixel_grid=True)
+    results["depth"] = results["depth"] * results["convergent_mask"].float()
+    if fill_holes:
+        depth = _closing3x3(results["depth"])
+        new_mask = depth > 1e-2
+        update = new_mask & ~results["convergent_mask"]
+        if update.any():
+            results["depth"][update] = depth[update]
+            results["convergent_mask"] = new_mask
+            results["distance"] = results["depth"] * results["ray_d_norm"]
+            results["points"] = results["ray_o"] + results["ray_d"] * results["distance"].unsqueeze(-1)
+    if detect_edges:
+        raise NotImplementedError("edge-aware sampling (locate_edge_points / render_edge_pixels) is outside the "
+                                  "accelerated hot path in this release; call with handle_edges=False")
+    results["edge_mask"] = torch.zeros_like(results["convergent_mask"])
+    return results
+
+
+def light_visibility(light_pos, points, sdf_network, inv_s, n_samples=128, is_training=True):
+    """Transmittance from the light to each surface point by a NeuS-style march (raytracer.py:669-729)."""
+    device = points.device
+    bs = points.shape[0]
+    delta = points - light_pos
+    length = torch.norm(delta, dim=-1, keepdim=True)
+    rays_d = delta / length
+    discard = 10
+    z = torch.linspace(0, 1, n_samples, device=device)[:-discard]
+    n = n_samples - discard
+    z = z.view(1, n) * length
+    dists = torch.cat([z[..., 1:] - z[..., :-1], torch.full((bs, 1), 1.0 / n, device=device)], dim=-1)
+    mid = z + dists * 0.5
+    pts = (light_pos + rays_d[..., None, :] * mid[..., :, None]).reshape(-1, 3)
+    dirs = rays_d[..., None, :].expand(bs, n, 3).reshape(-1, 3)
+    if hasattr(sdf_network, "get_sdf_normal"):
+        sdf, grad = sdf_network.get_sdf_normal(pts, is_training=is_training)
+        sdf = sdf.reshape(-1, 1)
+    else:
+        sdf, _, grad = sdf_network.get_all(pts, is_training=is_training)
+    cos = -F.relu(-(dirs * grad).sum(-1, keepdim=True))
+    half = cos * dists.reshape(-1, 1) * 0.5
+    k = inv_s.reshape(1, 1)
+    prev_cdf = torch.sigmoid((sdf - half) * k)
+    next_cdf = torch.sigmoid((sdf + half) * k)
+    alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).reshape(bs, n).clip(0.0, 1.0)
+    trans = torch.cumprod(torch.cat([torch.ones(bs, 1, device=device), 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
+    acc_map = (1.0 - (alpha * trans).sum(dim=-1, keepdim=True)).reshape(bs)
+    return acc_map if is_training else acc_map.clone().detach()
+
+
+def render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_samples=128, max_num_pts=2500,
+                            is_training=True):
+    """raytracer.py:732-777: adds results["vis"] [H,W] (0 outside the hit/edge mask)."""
+    dots_sh = list(results["convergent_mask"].shape)
+    mask = (results["convergent_mask"] | results["edge_mask"]).reshape(-1)
+    vis = torch.zeros(mask.shape, dtype=torch.float32, device=mask.device)
+    if mask.any():
+        pts = results["points"].reshape(-1, 3)[mask]
+        v = light_visibility(light_pos, pts, sdf_network, inv_s, n_samples=n_samples, is_training=is_training)
+        with torch.set_grad_enabled(is_training):
+            vis = vis.index_put((mask.nonzero(as_tuple=True)[0],), v)
+    results.update({"vis": vis.reshape(dots_sh)})
+
+
+def render_normal_and_color(results, sdf_network, color_network_dict, dino_network, render_fn, is_training=False,
+                            max_num_pts=320000, light_pos=None, roughness_warmup=False):
+    """raytracer.py:780-865: shades the convergent pixels and merges render_fn's dict into `results`."""
+    dots_sh = list(results["convergent_mask"].shape)
+    mask = results["convergent_mask"].reshape(-1)
+    empty = torch.zeros(0, dtype=torch.float32, device=mask.device)
+    if mask.any():
+        points = results["points"].reshape(-1, 3)[mask]
+        ray_d = results["ray_d"].reshape(-1, 3)[mask]
+        ray_o = results["ray_o"].reshape(-1, 3)[mask]
+        sdf, feature, normal = sdf_network.get_all(points, is_training=is_training)
+        dino_feature = dino_network(points, is_training=False)
+        if is_training:
+            points = reparam_points(points, normal.detach(), -ray_d.detach(), sdf)
+    else:
+        points = ray_d = ray_o = normal = feature = dino_feature = empty
+    with torch.set_grad_enabled(is_training):
+        lightdir = distance = None
+        if light_pos is not None:
+            if mask.any():
+                lightdir = F.normalize(points - light_pos, eps=1e-10)
+                distance = (points - light_pos).norm(dim=-1, keepdim=True)
+            else:
+                lightdir = empty
+        render_results = render_fn(mask, color_network_dict, ray_o, ray_d, points, normal, feature,
+                                   dino_f=dino_feature, is_training=is_training, lightdir=lightdir, distance=distance,
+                                   roughness_warmup=roughness_warmup)
+    for k, v in render_results.items():
+        v = v.reshape(dots_sh + [-1])
+        results[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
+
+
+def render_camera(camera, sdf_network, raytracer, color_network_dict, dino_network, render_fn, fill_holes=True,
+                  handle_edges=True, inv_s=0.0, render_visibility=False, max_num_pts=512, light_pos=None,
+                  roughness_warmup=False, indirect_warmup=False, is_training=False):
+    """raytracer.py:1198-1275.  Indirect lighting (render_indirect_lighting) and edge pixels are next-row
+    components: pass indirect_warmup=True, handle_edges=False."""
+    results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=fill_holes,
+                              detect_edges=handle_edges)
+    if render_visibility:
+        render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_samples=128,
+                                max_num_pts=max_num_pts, is_training=is_training)
+    render_normal_and_color(results, sdf_network, color_network_dict, dino_network, render_fn,
+                            is_training=is_training, max_num_pts=320000, light_pos=light_pos,
+                            roughness_warmup=roughness_warmup)
+    if not indirect_warmup:
+        raise NotImplementedError("one-bounce indirect lighting (render_indirect_lighting) is outside the "
+                                  "accelerated hot path in this release; call with indirect_warmup=True")
+    return results
+
+
+def render_camera_visibility(camera, sdf_network, raytracer, fill_holes=True, handle_edges=True, is_training=False,
+                             inv_s=0.0, render_visibility=False, max_num_pts=4000, light_pos=None):
+    """raytracer.py:1278-1310: trace + 256-sample visibility bake."""
+    results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=fill_holes,
+                              detect_edges=handle_edges)
+    if render_visibility:
+        render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_samples=256,
+                                max_num_pts=max_num_pts, is_training=is_training)
+    return results

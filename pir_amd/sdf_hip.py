@@ -66,3 +66,42 @@ class PackedSdf:
                                                   _lib.ptr(normal), _lib.ptr(scratch), scratch.numel(),
                                                   _lib.stream_ptr()), "pir_sdf_get_all")
         return sdf, feat, normal
+
+
+_bwd_scratch_cache = {}
+BWD_CHUNK_POINTS = 131072
+
+
+def backward_scratch_for(device, chunk_points: int = None) -> torch.Tensor:
+    chunk_points = chunk_points or BWD_CHUNK_POINTS
+    key = (torch.device(device).index, chunk_points)
+    buf = _bwd_scratch_cache.get(key)
+    if buf is None:
+        buf = torch.empty(_lib.lib().pir_sdf_backward_scratch_bytes(chunk_points), dtype=torch.uint8, device=device)
+        _bwd_scratch_cache[key] = buf
+    return buf
+
+
+def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: bool, chunk_points: int = None):
+    """dL/dW_l, dL/db_l (effective weights, lists of 9) and dL/dx for upstream grads of (sdf, feat, normal)."""
+    x = x.detach().reshape(-1, 3).contiguous().float()
+    M = x.shape[0]
+    dev = x.device
+    gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in _SDF_SHAPES]
+    gbs = [torch.zeros(s[0], dtype=torch.float32, device=dev) for s in _SDF_SHAPES]
+    gx = torch.zeros(M, 3, dtype=torch.float32, device=dev) if need_gx else None
+
+    def prep(g, shape):
+        if g is None:
+            return None
+        return g.detach().reshape(shape).contiguous().float()
+
+    g_sdf, g_feat, g_normal = prep(g_sdf, (M,)), prep(g_feat, (M, 256)), prep(g_normal, (M, 3))
+    scratch = backward_scratch_for(dev, chunk_points)
+    wp = (ctypes.c_void_p * 9)(*[t.data_ptr() for t in gws])
+    bp = (ctypes.c_void_p * 9)(*[t.data_ptr() for t in gbs])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pir_sdf_get_all_backward(
+            _lib.ptr(packed.buf), _lib.ptr(x), M, _lib.ptr(g_sdf), _lib.ptr(g_feat), _lib.ptr(g_normal), _lib.ptr(gx),
+            wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()), "pir_sdf_get_all_backward")
+    return gws, gbs, gx
