@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rays/s for one stage-2 style training step (sphere trace + light-visibility march +
+GGX shade, forward and backward, optimizer step) of an 800x800 view per GPU.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task description): whole-job rays/s, the roofline object of the
+dominant kernel (HIP-event timed inside the run) and the CPU baseline (the oracle, timed on the host cores on a
+bounded sample of the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_FLOP = 1049088          # SDF forward, all 257 outputs
+FWD_FLOP_SDF = 918016       # SDF forward, sdf output only
+PEAK_F32_MFMA = 157.3       # TFLOP/s, MI355X_MICROARCH.md chip table
+
+
+def build_step(res, rank, world, device):
+    from pir_amd import scene
+    from pir_amd.parallel import FlatGradBucket
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer.raytracer import RayTracer, render_camera
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+
+    sdf, mats, dino = scene.build_networks(seed=0, device=device)
+    cam = scene.make_camera(res, res, view=rank, n_views=world, device=device)
+    tracer = RayTracer()
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    inv_s = torch.full((1, 1), scene.INV_S, device=device)
+    lr = scene.MODEL_CONFIG["lr"]
+    opts = [torch.optim.Adam(sdf.parameters(), lr=lr["sdf_network"])]
+    for k in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
+        opts.append(torch.optim.Adam(mats[k].parameters(), lr=lr[k]))
+    pl = mats["point_light_network"]
+    opts.append(torch.optim.Adam([{"params": [pl.light], "lr": 2e-5},
+                                  {"params": list(pl.light_offset.parameters()), "lr": 1e-4}]))
+    params = [p for o in opts for g in o.param_groups for p in g["params"]]
+    bucket = FlatGradBucket(params) if world > 1 else None
+    info = {}
+
+    def step():
+        for o in opts:
+            o.zero_grad(set_to_none=True)
+        light_pos = cam.get_light_pos(pl.offset)
+        results = render_camera(cam, sdf, tracer, mats, dino, render_fn, fill_holes=False, handle_edges=False,
+                                inv_s=inv_s, render_visibility=True, max_num_pts=512, light_pos=light_pos,
+                                indirect_warmup=True, is_training=True)
+        loss = scene.step_loss(results)
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce()
+        for o in opts:
+            o.step()
+        info["hits"] = results["convergent_mask"]
+        info["loss"] = loss.detach()
+
+    return step, info, (sdf, mats, dino)
+
+
+def cpu_baseline(res, nets):
+    """The oracle (a port of the reference path) on the host cores: one res x res view of the same scene,
+    forward + backward.  Bounded sample: 800^2 does not fit one autograd graph on the CPU."""
+    from oracle import pir_oracle as O
+    from pir_amd import scene
+    sdf, mats, dino = nets
+    cpu = lambda m: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}  # noqa: E731
+    sdf_state = cpu(sdf)
+    layers = O.mlp_layers(sdf_state)
+    omats = {}
+    for k in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
+        omats[k] = dict(layers=O.mlp_layers(cpu(mats[k])), cfg=scene.MODEL_CONFIG[k])
+    odino = dict(layers=O.mlp_layers({k: v.detach().cpu() for k, v in dino.state_dict().items()}),
+                 cfg=scene.MODEL_CONFIG["dino_network"])
+    tables = O.load_ggx_tables(os.path.join(ROOT, "pir_amd", "renderer", "ggx"))
+    c = scene.make_camera(res, res)
+    cam = O.CameraRays(res, res, c.K, c.W2C)
+    light = torch.tensor(scene.LIGHT_INTENSITY, requires_grad=True)
+    off = torch.tensor([list(scene.LIGHT_OFFSET)], requires_grad=True)
+    t0 = time.perf_counter()
+    r = O.render_view(cam, layers, omats, odino, tables, light, light_offset=off,
+                      inv_s=torch.tensor([[scene.INV_S]]), n_vis_samples=128, is_training=True)
+    O.step_loss(r).backward()
+    dt = time.perf_counter() - t0
+    return {"value": res * res / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one {res}x{res} view of the same scene (same focal/height ratio, {int(r['convergent_mask'].sum())} hits), "
+                      f"trace + visibility(128) + shade fwd+bwd in {dt:.1f} s, torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--res", type=int, default=800)
+    ap.add_argument("--cpu-res", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from pir_amd import _lib
+    L = _lib.lib()
+    step, info, nets = build_step(args.res, rank, world, device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    L.pir_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    L.pir_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n = _lib.lib().pir_profile_read
+    nk = 9
+    launches = (ctypes.c_long * nk)()
+    total_ms = (ctypes.c_double * nk)()
+    units = (ctypes.c_double * nk)()
+    n(nk, launches, total_ms, units)
+    names = ["sdf_eval_kernel(forward)", "sdf_eval_kernel(get_all)", "trace_step_kernel", "sampler_kernel",
+             "bisect_kernel", "bwd_sweep_kernel", "wgrad_kernel", "ggx_forward_kernel", "ggx_backward_kernel"]
+    # algorithmic FLOP per unit (point): get_all = forward + reverse sweep; bwd sweep = dh chains of both passes
+    # (2 x forward); wgrad = 2 products (2 x forward).  Visibility samples (no feature head) dominate the counts,
+    # so the sdf-only forward figure is used for them.
+    alg = {1: 2 * FWD_FLOP_SDF, 5: 2 * FWD_FLOP_SDF, 6: 2 * FWD_FLOP_SDF}
+    dom = max(alg, key=lambda k: total_ms[k])
+    roofline = None
+    if launches[dom] > 0 and total_ms[dom] > 0:
+        achieved = alg[dom] * units[dom] / (total_ms[dom] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": names[dom], "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                    "launches": int(launches[dom]), "avg_launch_ms": round(total_ms[dom] / launches[dom], 4),
+                    "flop_per_point": alg[dom], "points_per_launch": round(units[dom] / launches[dom], 1)}
+    breakdown = {names[i]: {"launches": int(launches[i]), "ms_per_step": round(total_ms[i] / args.steps, 3)}
+                 for i in range(nk) if launches[i]}
+
+    if rank == 0:
+        rays = args.res * args.res * world * args.steps
+        out = {"metric": "rays/sec fwd+bwd (trace+GGX+shadow) at 800x800", "value": round(rays / dt, 1),
+               "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{args.res}x{args.res} view per GPU: sphere trace + light-visibility march "
+                                      "(128 samples) + GGX shade, fwd+bwd + Adam step, random-init nets "
+                                      "(configs/model_config.json), offset point light",
+                          "views": world, "hits_per_view": int(info["hits"].sum().item()),
+                          "parallelism": f"dp{world} (one view per GPU, flat RCCL grad all-reduce)"},
+               "roofline": roofline, "kernels": breakdown}
+        if world == 1 and not args.no_cpu_baseline:
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_res, nets)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

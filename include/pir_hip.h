@@ -97,6 +97,17 @@ int pir_ggx_backward(long P, const float* light, int light_is_rgb, int direct_ra
                      float* g_normal, float* g_lightdir, float* g_viewdir, float* g_kd, float* g_ks, float* g_alpha,
                      void* stream);
 
+/* ---- measurement aid (no counterpart in the reference) ------------------------------------------------ */
+
+/* Kernel families timed by the optional HIP-event profiler. */
+enum { PIR_K_SDF_EVAL = 0, PIR_K_SDF_GETALL = 1, PIR_K_TRACE_STEP = 2, PIR_K_SAMPLER = 3, PIR_K_BISECT = 4,
+       PIR_K_BWD_SWEEP = 5, PIR_K_WGRAD = 6, PIR_K_GGX_FWD = 7, PIR_K_GGX_BWD = 8, PIR_K_COUNT = 9 };
+/* When enabled every kernel launch of the families above is bracketed by hipEvents on its stream. */
+int pir_profile_enable(int on);
+/* Synchronises and returns, per family id < n_ids, the number of launches, their summed duration (ms) and the
+ * summed units (points) they processed (0 for the tracer kernels, whose list sizes live on the device). */
+int pir_profile_read(int n_ids, long* launches, double* total_ms, double* units);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,10 @@ def _declare(L):
     L.pir_ggx_forward.argtypes = [lg, vp, i32, i32] + [vp] * 8 + [i32, vp, i32, vp, vp, vp, vp]
     L.pir_ggx_backward.restype = i32
     L.pir_ggx_backward.argtypes = [lg, vp, i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 10 + [vp]
+    L.pir_profile_enable.restype = i32
+    L.pir_profile_enable.argtypes = [i32]
+    L.pir_profile_read.restype = i32
+    L.pir_profile_read.argtypes = [i32, ctypes.POINTER(lg), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
     for name, args in _OPTIONAL.items():
         if hasattr(L, name):
             fn = getattr(L, name)

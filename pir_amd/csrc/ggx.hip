@@ -290,6 +290,7 @@ int pir_ggx_forward(long P, const float* light, int light_is_rgb, int direct_rad
       !out_diffuse || !out_specular || !out_rgb || n_rough <= 0 || n_diff <= 0)
     return PIR_ERR_ARG;
   GgxTables tb{table_rough, n_rough, table_diff, n_diff};
+  PirProfScope prof(PIR_K_GGX_FWD, (double)P, stream);
   hipLaunchKernelGGL(ggx_forward_kernel, dim3(ggx_grid(P)), dim3(kGgxBlock), 0, (hipStream_t)stream, P, light,
                      light_is_rgb, direct_radiance, distance, normal, lightdir, viewdir, kd, ks, alpha, tb, out_diffuse,
                      out_specular, out_rgb);
@@ -309,6 +310,7 @@ int pir_ggx_backward(long P, const float* light, int light_is_rgb, int direct_ra
       !g_ks || !g_alpha || n_rough <= 0 || n_diff <= 0)
     return PIR_ERR_ARG;
   GgxTables tb{table_rough, n_rough, table_diff, n_diff};
+  PirProfScope prof(PIR_K_GGX_BWD, (double)P, stream);
   hipLaunchKernelGGL(ggx_backward_kernel, dim3(ggx_grid(P)), dim3(kGgxBlock), 0, (hipStream_t)stream, P, light,
                      light_is_rgb, direct_radiance, distance, normal, lightdir, viewdir, kd, ks, alpha, tb,
                      grad_diffuse, grad_specular, g_light, g_distance, g_normal, g_lightdir, g_viewdir,

@@ -19,3 +19,12 @@ static inline int pir_num_cus() {
   }
   return cus[dev];
 }
+
+// kernel families for the optional event profiler (prof.hip)
+extern "C" int pir_prof_begin(int id, double units, void* stream);
+extern "C" void pir_prof_end(int token, void* stream);
+struct PirProfScope {
+  int tok; void* st;
+  PirProfScope(int id, double units, void* stream) : tok(pir_prof_begin(id, units, stream)), st(stream) {}
+  ~PirProfScope() { pir_prof_end(tok, st); }
+};

@@ -258,6 +258,7 @@ extern "C" int pir_internal_bwd_sweep(const void* packed, const float* x, const 
   const int ntiles = (chunk_n + kTilePts - 1) / kTilePts;
   const int resident = 2 * pir_num_cus();
   const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
+  PirProfScope prof(PIR_K_BWD_SWEEP, (double)chunk_n, stream);
   hipLaunchKernelGGL(bwd_sweep_kernel, dim3(grid), dim3(kThreads), 0, (hipStream_t)stream, pk, x, g_sdf, g_feat,
                      g_nrm, chunk_base, chunk_n, *sc, g_x);
   return pir_check_launch();

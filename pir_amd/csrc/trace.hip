@@ -328,16 +328,23 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
   const long tiles = (n_rays + kWgPts - 1) / kWgPts;
   const long resident = 2L * pir_num_cus();
   const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
-  for (int it = 0; it <= sphere_tracing_iters; ++it)
+  for (int it = 0; it <= sphere_tracing_iters; ++it) {
+    PirProfScope prof(PIR_K_TRACE_STEP, 0.0, stream_);
     hipLaunchKernelGGL(trace_step_kernel, dim3(grid), dim3(kThreads), 0, stream, pk, it, sphere_tracing_iters,
                        sdf_threshold, ray_d, max_dis, work_mask, points, sdf, distance, convergent, ws);
+  }
   const unsigned sgrid = (unsigned)(n_rays < resident ? n_rays : resident);
+  {
+  PirProfScope prof(PIR_K_SAMPLER, 0.0, stream_);
   hipLaunchKernelGGL(sampler_kernel, dim3(sgrid), dim3(kThreads), 0, stream, pk, sphere_tracing_iters, n_steps,
                      (int)chunk, nchunks, ray_o, ray_d, min_dis, max_dis, points, sdf, distance, convergent, ws);
-  for (int it = 0; it <= max_bisect; ++it)
+  }
+  for (int it = 0; it <= max_bisect; ++it) {
+    PirProfScope prof(PIR_K_BISECT, 0.0, stream_);
     hipLaunchKernelGGL(bisect_kernel, dim3(grid), dim3(kThreads), 0, stream, pk, it, it == max_bisect ? 1 : 0,
                        max_bisect, sdf_threshold, (int)chunk, nchunks, ray_o, ray_d, points, sdf, distance, convergent,
                        ws);
+  }
   return pir_check_launch();
 }
 

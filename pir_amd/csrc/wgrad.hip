@@ -240,8 +240,11 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
           j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.scale = 1.0f; j.bias = itl == 0;
         }
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * kKSplit), dim3(kWgThreads), 0, stream, jobs, n_rows, slabs,
-                       bias_slabs);
+    {
+      PirProfScope prof(PIR_K_WGRAD, (double)n, stream_);
+      hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * kKSplit), dim3(kWgThreads), 0, stream, jobs, n_rows, slabs,
+                         bias_slabs);
+    }
     hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
                        g_sdf ? g_sdf + base : nullptr, n, row0);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(jobs.n + 1), dim3(256), 0, stream, jobs, slabs, bias_slabs, row0, out);
