@@ -13,7 +13,7 @@ constexpr int kWgThreads = 256;
 constexpr int kWgTile = 128;     // C tile edge
 constexpr int kWgKPts = 32;      // points per K step staged in LDS
 constexpr int kMaxJobs = 40;
-constexpr int kKSplit = 16;
+constexpr int kKSplitMax = 64;
 
 struct WgJob {
   const float* X1; const float* Y1;   // product 1 (Zb, H)
@@ -27,9 +27,11 @@ struct WgJob {
 };
 struct WgJobs { WgJob j[kMaxJobs]; int n; };
 
-__device__ __forceinline__ void stage_tile(float (*dst)[kWgTile], const float* __restrict__ src, int ld, int col0,
-                                           int row0, int rows_valid) {
-  // 32 rows x 128 floats; thread t moves 4 float4
+struct TileRegs { f32x4 v[4]; };
+
+// 32 rows x 128 floats of a [rows][ld] array -> registers (thread t holds float4 #(q*256 + t), q < 4)
+__device__ __forceinline__ void load_tile(TileRegs& t, const float* __restrict__ src, int ld, int col0, int row0,
+                                          int rows_valid) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = q * kWgThreads + threadIdx.x;
@@ -37,18 +39,28 @@ __device__ __forceinline__ void stage_tile(float (*dst)[kWgTile], const float* _
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (col0 + 4 * c4 < ld && (rows_valid < 0 || row0 + r < rows_valid))
       v = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + r) * ld + col0 + 4 * c4);
-    *reinterpret_cast<f32x4*>(&dst[r][4 * c4]) = v;
+    t.v[q] = v;
+  }
+}
+__device__ __forceinline__ void store_tile(float (*dst)[kWgTile], const TileRegs& t) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * kWgThreads + threadIdx.x;
+    *reinterpret_cast<f32x4*>(&dst[idx >> 5][4 * (idx & 31)]) = t.v[q];
   }
 }
 
+// One workgroup = one (job, K slice): C tile 128x128 over the slice's points, both products of the job.
+// The operands of step s+1 are fetched into registers while the MFMAs of step s run from LDS.
 __global__ void __launch_bounds__(kWgThreads)
-wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, float* __restrict__ slabs, float* __restrict__ bias_slabs) {
+wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __restrict__ slabs,
+             float* __restrict__ bias_slabs) {
   __shared__ float Xs[kWgKPts][kWgTile];
   __shared__ float Ys[kWgKPts][kWgTile];
-  const int job_id = blockIdx.x / kKSplit, ks = blockIdx.x % kKSplit;
+  const int job_id = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
   const WgJob jb = jobs.j[job_id];
   const int total_it = n_rows / kWgKPts;
-  const int it0 = (int)((long)ks * total_it / kKSplit), it1 = (int)((long)(ks + 1) * total_it / kKSplit);
+  const int it0 = (int)((long)ks * total_it / ksplit), it1 = (int)((long)(ks + 1) * total_it / ksplit);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int wr = wv >> 1, wc = wv & 1, lo = lane & 31, kh = lane >> 5;
   f32x16 acc[2][2];
@@ -61,34 +73,39 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, float* __restrict__ s
   float bsum = 0.f;
   const int ncols_y = jb.ldy - jb.i0 < kWgTile ? jb.ldy - jb.i0 : kWgTile;
   const bool wave_has_cols = 64 * wc < ncols_y;
-  for (int it = it0; it < it1; ++it) {
-    const int row0 = it * kWgKPts;
-#pragma unroll 1
-    for (int prod = 0; prod < 2; ++prod) {
-      const float* X = prod ? jb.X2 : jb.X1;
-      const float* Y = prod ? jb.Y2 : jb.Y1;
-      if (!X) continue;
-      __syncthreads();
-      stage_tile(Xs, X, 256, jb.o0, row0, prod ? -1 : jb.x1_rows);
-      stage_tile(Ys, Y, jb.ldy, jb.i0, row0, -1);
-      __syncthreads();
-      if (prod == 0 && jb.bias) {
-        const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+  const int nprod = jb.X2 ? 2 : 1;
+  const int nsteps = (it1 - it0) * nprod;
+  TileRegs tx, ty;
+  auto fetch = [&](int step) {
+    const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts;
+    load_tile(tx, prod ? jb.X2 : jb.X1, 256, jb.o0, row0, prod ? -1 : jb.x1_rows);
+    load_tile(ty, prod ? jb.Y2 : jb.Y1, jb.ldy, jb.i0, row0, -1);
+  };
+  if (nsteps > 0) fetch(0);
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();
+    store_tile(Xs, tx);
+    store_tile(Ys, ty);
+    __syncthreads();
+    if (step + 1 < nsteps) fetch(step + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (jb.bias && step % nprod == 0) {
+      const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) bsum += Xs[16 * half + r][col];
-      }
-      if (wave_has_cols) {
+      for (int r = 0; r < 16; ++r) bsum += Xs[16 * half + r][col];
+    }
+    if (wave_has_cols) {
 #pragma unroll
-        for (int s = 0; s < kWgKPts / 2; ++s) {
-          const float a0 = Xs[2 * s + kh][64 * wr + lo], a1 = Xs[2 * s + kh][64 * wr + 32 + lo];
-          const float b0 = Ys[2 * s + kh][64 * wc + lo], b1 = Ys[2 * s + kh][64 * wc + 32 + lo];
-          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
+      for (int s = 0; s < kWgKPts / 2; ++s) {
+        const float a0 = Xs[2 * s + kh][64 * wr + lo], a1 = Xs[2 * s + kh][64 * wr + 32 + lo];
+        const float b0 = Ys[2 * s + kh][64 * wc + lo], b1 = Ys[2 * s + kh][64 * wc + 32 + lo];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   float* slab = slabs + ((size_t)ks * jobs.n + job_id) * kWgTile * kWgTile;
 #pragma unroll
@@ -112,14 +129,26 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, float* __restrict__ s
 }
 
 // row 0 of dW8 and db8[0]:  sum_pts (g_sdf a7 + a7-tangent),  sum_pts g_sdf   -> partial[block][257]
-constexpr int kRow0Blocks = 128;
+constexpr int kRow0Blocks = 1024;
 __global__ void __launch_bounds__(256)
 row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const float* __restrict__ g_sdf /* chunk-local or null */,
             int chunk_n, float* __restrict__ partial) {
   const int col = threadIdx.x;
   const int r0 = (int)((long)blockIdx.x * chunk_n / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * chunk_n / gridDim.x);
   float s = 0.f, sg = 0.f;
-  for (int r = r0; r < r1; ++r) {
+  int r = r0;
+  for (; r + 4 <= r1; r += 4) {   // 8 independent loads in flight per thread
+    float a[4], d[4], g[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = A7[(size_t)(r + u) * 256 + col];
+      d[u] = Ad7[(size_t)(r + u) * 256 + col];
+      g[u] = g_sdf ? g_sdf[r + u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += g[u] * a[u] + d[u]; sg += g[u]; }
+  }
+  for (; r < r1; ++r) {
     const float g = g_sdf ? g_sdf[r] : 0.f;
     s += g * A7[(size_t)r * 256 + col] + Ad7[(size_t)r * 256 + col];
     sg += g;
@@ -131,7 +160,7 @@ row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const f
 struct GradOut { float* w[9]; float* b[9]; };
 
 __global__ void __launch_bounds__(256)
-wgrad_reduce_kernel(WgJobs jobs, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
+wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                     const float* __restrict__ row0_partial, GradOut out) {
   const int job_id = blockIdx.x;
   if (job_id == jobs.n) {   // the row-0 block
@@ -149,23 +178,22 @@ wgrad_reduce_kernel(WgJobs jobs, const float* __restrict__ slabs, const float* _
     const int o = jb.o0 + e / kWgTile, i = jb.i0 + e % kWgTile;
     if (o >= jb.rows || i >= jb.cols) continue;
     float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < kKSplit; ++k) s += base[k * stride + e];
+    for (int k = 0; k < ksplit; ++k) s += base[k * stride + e];
     out.w[jb.layer][(size_t)(jb.row_off + o) * jb.cols + i] += jb.scale * s;
   }
   if (jb.bias && threadIdx.x < kWgTile) {
     const int o = jb.o0 + threadIdx.x;
     if (o < jb.rows) {
       float s = 0.f;
-      for (int k = 0; k < kKSplit; ++k) s += bias_slabs[((size_t)k * jobs.n + job_id) * kWgTile + threadIdx.x];
+      for (int k = 0; k < ksplit; ++k) s += bias_slabs[((size_t)k * jobs.n + job_id) * kWgTile + threadIdx.x];
       out.b[jb.layer][jb.row_off + o] += s;
     }
   }
 }
 
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
-constexpr size_t kSlabBytes = (size_t)kKSplit * kMaxJobs * kWgTile * kWgTile * 4;
-constexpr size_t kBiasSlabBytes = (size_t)kKSplit * kMaxJobs * kWgTile * 4;
+constexpr size_t kSlabBytes = (size_t)kKSplitMax * kMaxJobs * kWgTile * kWgTile * 4;
+constexpr size_t kBiasSlabBytes = (size_t)kKSplitMax * kMaxJobs * kWgTile * 4;
 constexpr size_t kRow0Bytes = (size_t)kRow0Blocks * 257 * 4;
 constexpr size_t kFixedBytes = ((kSlabBytes + 255) & ~(size_t)255) + ((kBiasSlabBytes + 255) & ~(size_t)255) +
                                ((kRow0Bytes + 255) & ~(size_t)255);
@@ -213,6 +241,9 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
     const int n_rows = (n + 31) / 32 * 32;
     int rc = pir_internal_bwd_sweep(packed, x, g_sdf, g_feat, g_normal, base, n, &sc, g_x, stream_);
     if (rc != PIR_OK) return rc;
+    // K slices of >= 8 staged steps each; many more workgroups than CUs so the dispatcher balances them
+    int ksplit = n_rows / kWgKPts / 8;
+    ksplit = ksplit < 1 ? 1 : (ksplit > kKSplitMax ? kKSplitMax : ksplit);
     WgJobs jobs;
     jobs.n = 0;
     for (int l = 0; l < 8; ++l) {
@@ -242,12 +273,13 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
     }
     {
       PirProfScope prof(PIR_K_WGRAD, (double)n, stream_);
-      hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * kKSplit), dim3(kWgThreads), 0, stream, jobs, n_rows, slabs,
-                         bias_slabs);
+      hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * ksplit), dim3(kWgThreads), 0, stream, jobs, n_rows, ksplit,
+                         slabs, bias_slabs);
     }
     hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
                        g_sdf ? g_sdf + base : nullptr, n, row0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(jobs.n + 1), dim3(256), 0, stream, jobs, slabs, bias_slabs, row0, out);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(jobs.n + 1), dim3(256), 0, stream, jobs, ksplit, slabs, bias_slabs,
+                       row0, out);
     rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
   }

@@ -10,6 +10,10 @@ import torch
 
 from . import sdf_hip
 
+SKIP_ZERO_MIN_POINTS = 1 << 16   # below this the mask + host read-back costs more than it can save
+SKIP_ZERO_FRACTION = 0.9         # compact when fewer than this fraction of the points carry gradient
+stats = {}
+
 
 class _SdfGetAll(torch.autograd.Function):
     @staticmethod
@@ -36,8 +40,32 @@ class _SdfGetAll(torch.autograd.Function):
     def backward(ctx, g_sdf, g_feat, g_nrm):
         (x,) = ctx.saved_tensors
         want_feature, want_normal = ctx.want
-        gws, gbs, gx = sdf_hip.get_all_backward(ctx.packed, x, g_sdf, g_feat if want_feature else None,
-                                                g_nrm if want_normal else None, ctx.need_gx)
+        g_feat = g_feat if want_feature else None
+        g_nrm = g_nrm if want_normal else None
+        # Points whose upstream gradients are all exactly zero contribute exactly nothing (Zb = 0 and the tangent
+        # is 0, so both weight-gradient products and dL/dx vanish): drop them before the sweeps.  In the light
+        # march these are the samples whose sigmoid saturated in fp32 (most of free space for a trained inv_s).
+        M = x.shape[0]
+        sel = None
+        if g_feat is None and M >= SKIP_ZERO_MIN_POINTS and (g_sdf is not None or g_nrm is not None):
+            nz = torch.zeros(M, dtype=torch.bool, device=x.device)
+            if g_sdf is not None:
+                nz |= g_sdf.reshape(M) != 0
+            if g_nrm is not None:
+                nz |= (g_nrm.reshape(M, 3) != 0).any(dim=-1)
+            n_nz = int(nz.sum().item())
+            stats["last_nonzero_fraction"] = n_nz / max(1, M)
+            if n_nz < SKIP_ZERO_FRACTION * M:
+                sel = nz.nonzero(as_tuple=True)[0]
+        if sel is not None:
+            pick = lambda g, w: None if g is None else g.reshape(M, *w).index_select(0, sel)  # noqa: E731
+            gws, gbs, gx_sel = sdf_hip.get_all_backward(ctx.packed, x.index_select(0, sel), pick(g_sdf, ()),
+                                                        None, pick(g_nrm, (3,)), ctx.need_gx)
+            gx = None
+            if ctx.need_gx:
+                gx = torch.zeros_like(x).index_copy_(0, sel, gx_sel)
+        else:
+            gws, gbs, gx = sdf_hip.get_all_backward(ctx.packed, x, g_sdf, g_feat, g_nrm, ctx.need_gx)
         return (None, None, None, gx, *gws, *gbs)
 
 
