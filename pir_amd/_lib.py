@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpir_hip.so")
+LIB_PATH = os.environ.get("PIR_HIP_LIB", os.path.join(_HERE, "libpir_hip.so"))  # override: development A/B builds
 _lib = None
 
 PIR_OK = 0

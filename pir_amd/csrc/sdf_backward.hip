@@ -98,13 +98,14 @@ __device__ __forceinline__ void pe_xbar(const Lds& lds, const f32x16 (&accpe)[kS
   }
 }
 
-__global__ void __launch_bounds__(kThreads, 1)
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restrict__ g_sdf,
                  const float* __restrict__ g_feat, const float* __restrict__ g_nrm, long chunk_base, int chunk_n,
                  BwdScratch sc, float* __restrict__ g_x) {
   __shared__ Lds lds;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   const int ntiles = (chunk_n + kTilePts - 1) / kTilePts;
+  if (ntiles > 2 * pk.num_cus) stagger_start(pk.num_cus);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // Launder the lane half so that hipcc does not hoist the hundreds of per-(layer, tile, group) scratch
     // addresses out of this loop (they would all spill).
@@ -120,8 +121,8 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       if (g_sdf) gs = g_sdf[P];
     }
     if (w == 0) write_pe(lds, 0, x0, x1, x2);
-    else write_pe_tangent(lds, 1, x0, x1, x2, nb0, nb1, nb2);
-    store_pe_cols(lds, w, w == 0 ? sc.E : sc.Ed, row);
+    else if (w == 1) write_pe_tangent(lds, 1, x0, x1, x2, nb0, nb1, nb2);
+    if (w < 2) store_pe_cols(lds, w, w == 0 ? sc.E : sc.Ed, row);
     __syncthreads();
 
     f32x16 acc[kSets][kTPW];
@@ -216,9 +217,9 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       if (m >= 1) {
         zero_acc(acc);
         gemm_phase<kTPW>(pk.mats, kRev[m], kTPW * w, lds, 0, acc);
-        if (m == 4) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+        if (m == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
       } else {
-        gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
+        if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
       }
       __syncthreads();
     }
@@ -227,10 +228,10 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     if (g_x) {
       float xb[3] = {0.f, 0.f, 0.f};
       if (w == 0) pe_xbar<0>(lds, accpe, nb0, nb1, nb2, h, xb);
-      else pe_xbar<1>(lds, accpe, nb0, nb1, nb2, h, xb);
+      else if (w == 1) pe_xbar<1>(lds, accpe, nb0, nb1, nb2, h, xb);
 #pragma unroll
       for (int c = 0; c < 3; ++c) xb[c] += __shfl_xor(xb[c], 32);
-      if (lane < 32) {
+      if (lane < 32 && w < 2) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) lds.red[w][0][lane][1 + c] = xb[c];
       }
@@ -255,6 +256,7 @@ extern "C" int pir_internal_bwd_sweep(const void* packed, const float* x, const 
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
+  pk.num_cus = pir_num_cus();
   const int ntiles = (chunk_n + kTilePts - 1) / kTilePts;
   const int resident = 2 * pir_num_cus();
   const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);

@@ -17,11 +17,16 @@ namespace pir {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kThreads = 128;      // 2 waves
+#ifndef PIR_WAVES
+#define PIR_WAVES 4
+#endif
+constexpr int kWaves = PIR_WAVES;   // waves per workgroup (2 or 4); two workgroups per CU -> kWaves/2 waves per SIMD
+constexpr int kThreads = 64 * kWaves;
+constexpr int kWavesPerSimd = kWaves / 2;
 constexpr int kTilePts = 32;       // points per operand set
 constexpr int kSets = 2;           // operand sets per workgroup
 constexpr int kWgPts = 64;         // points per workgroup when both sets carry points
-constexpr int kTPW = 4;            // output tiles per wave
+constexpr int kTPW = 8 / kWaves;   // output tiles per wave
 constexpr int kActKB = 32;         // k-blocks (4 k-steps = 8 features) of the 256-feature region
 constexpr int kPeKB = 5;           // k-blocks of the positional-encoding region (20 slots x 2 halves)
 constexpr int kSetKB = kActKB + kPeKB;
@@ -68,7 +73,23 @@ constexpr int kVecFloats = 10 * 256 + 4;
 struct SdfPacked {
   const f32x4* mats;   // kPackedF4 entries
   const float* vecs;   // kVecFloats entries: bias of lin0..lin7, b8[1..256], w8 row 0, b8[0]
+  int num_cus;         // CUs of the device (for the start stagger below)
 };
+
+// The two workgroups that share a CU run the same program on the same amount of work, so they stay in lockstep:
+// both are in their (VALU) epilogues at the same time and the matrix pipe idles.  Delaying the second workgroup
+// of each CU by about half a layer period lets one workgroup's epilogue run under the other's MFMAs.  Which
+// blocks share a CU is not defined by HIP; blocks [num_cus, 2 num_cus) are the observed second residents -- a
+// wrong guess only loses the overlap, never correctness.
+__device__ __forceinline__ void stagger_start(int num_cus) {
+#ifndef PIR_NO_STAGGER
+  const int b = blockIdx.x;
+  if (b >= num_cus && b < 2 * num_cus) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+}
 
 // ---- feature <-> (k-step, half) maps ---------------------------------------------------------
 // C/D layout of the 32x32 MFMA: lane = 32*h + point, register r holds tile row (r&3) + 8*(r>>2) + 4*h.
@@ -91,7 +112,7 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // ---- LDS image ------------------------------------------------------------------------------
 struct Lds {
   f32x4 act[kSets][kSetKB][64];   // 2 x 37 KB
-  float red[2][kSets][kTilePts][4];  // cross-wave reductions (sdf, normal)
+  float red[kWaves][kSets][kTilePts][4];  // cross-wave reductions (sdf: all waves; normal / dx: waves 0,1)
 };
 static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU must fit in 160 KB");
 
@@ -119,8 +140,12 @@ __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod 
                                            int lds_kb0, f32x16 (&acc)[kSets][NT]) {
   const int lane = lane_id();
   const f32x4* w = mats + p.off + (size_t)tile0 * kTileKB + lane;
-  const int kb_stride = p.ntiles * kTileKB;
+  int kb_stride = p.ntiles * kTileKB;
   const int last = p.nkb - 1;
+#ifdef PIR_ABLATE_WLOAD   // diagnosis build: every k-block re-reads the same 1 KB (no L2 weight stream)
+  w = mats + lane;
+  kb_stride = 0;
+#endif
   f32x4 wa[NT], wb[NT], ba[kSets], bb[kSets];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wa[t] = w[t * kTileKB];
@@ -170,15 +195,21 @@ __device__ __forceinline__ f32x4 load_feat4(const float* __restrict__ v, int T, 
 }
 
 // softplus(beta=100, threshold=20) and its derivative sigma(100 z); reference: src/network.py:79.
-// t = exp(-|100 z|) via v_exp_f32; log via v_log_f32: absolute error of the activation ~1e-9.
+//   softplus(z) = max(z,0) + ln2/100 * log2(1 + 2^(-|z| * 100 log2 e))
+// on the bare v_exp_f32 / v_log_f32 (the log argument is in [1,2]: none of the denormal fix-ups that
+// __expf/__logf expand to are needed).  For 100 z > 20 the log term is exactly 0 in fp32, which is PyTorch's
+// threshold branch.  Absolute error of the activation ~1e-9.
 __device__ __forceinline__ float softplus100(float z) {
-  float u = 100.f * z;
-  float t = __expf(-fabsf(u));
-  float sp = fmaxf(z, 0.f) + 0.01f * __logf(1.f + t);
-  return u > 20.f ? z : sp;
+#ifdef PIR_ABLATE_ACT
+  return z;
+#endif
+  const float t = __builtin_amdgcn_exp2f(fabsf(z) * -144.26950408889634f);
+  return fmaf(0.0069314718055994531f, __builtin_amdgcn_logf(1.0f + t), fmaxf(z, 0.f));
 }
 // sigma(100 z) recovered from a = softplus100(z): 1 - exp(-100 a)  (exact identity; 1 in the linear branch)
-__device__ __forceinline__ float dsoftplus_from_act(float a) { return 1.f - __expf(-100.f * a); }
+__device__ __forceinline__ float dsoftplus_from_act(float a) {
+  return 1.f - __builtin_amdgcn_exp2f(a * -144.26950408889634f);
+}
 
 // sin/cos with a 3-term Cody-Waite reduction by pi/2 and the Cephes single-precision kernels
 // (|error| ~1e-7 for |a| < ~1e4; PE arguments are at most 32 |x|).  Avoids the Payne-Hanek slow

@@ -84,7 +84,7 @@ __global__ void pack_kernel(PackArgs a, float* __restrict__ mats, float* __restr
 enum { kWantFeat = 1, kWantNormal = 2 };
 
 template <int FLAGS>
-__global__ void __launch_bounds__(kThreads, 1)
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __restrict__ sdf, float* __restrict__ feat,
                 float* __restrict__ normal, f32x4* __restrict__ scratch_all) {
   __shared__ Lds lds;
@@ -92,9 +92,10 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   const long ntiles = (M + kWgPts - 1) / kWgPts;
   f32x4* scratch = kNormal ? scratch_all + (size_t)blockIdx.x * kScratchWgF4 : nullptr;
+  stagger_start(pk.num_cus);
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long base = tile * kWgPts;
-    const long P = base + 32 * w + j;
+    const long P = base + 32 * (w & 1) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (P < M) { x0 = x[3 * P]; x1 = x[3 * P + 1]; x2 = x[3 * P + 2]; }
     forward_hidden<kNormal>(lds, pk, x0, x1, x2, scratch);
@@ -173,6 +174,7 @@ static SdfPacked make_packed(const void* packed) {
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
+  pk.num_cus = pir_num_cus();
   return pk;
 }
 

@@ -20,7 +20,7 @@ template <bool STORE>
 __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, float x0, float x1, float x2,
                                                f32x4* __restrict__ scratch) {
   const int w = wave_id();
-  write_pe(lds, w, x0, x1, x2);
+  if (w < kSets) write_pe(lds, w, x0, x1, x2);   // wave w encodes the points of set w
   __syncthreads();
   f32x16 acc[kSets][kTPW];
 #pragma nounroll
@@ -67,7 +67,10 @@ __device__ __forceinline__ void sdf_head(Lds& lds, const SdfPacked& pk) {
   }
 }
 __device__ __forceinline__ float read_sdf(const Lds& lds, const SdfPacked& pk, int set, int j) {
-  return lds.red[0][set][j][0] + lds.red[1][set][j][0] + pk.vecs[kVecB80];
+  float s = pk.vecs[kVecB80];
+#pragma unroll
+  for (int w = 0; w < kWaves; ++w) s += lds.red[w][set][j][0];
+  return s;
 }
 
 // lin8 rows 1..256 (+bias) -> feat[(base + 32*set + j) * 256 + f]
@@ -178,19 +181,19 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
   for (int l = 7; l >= 1; --l) {
     zero_acc(acc);
     gemm_phase<kTPW>(pk.mats, kRev[l], kTPW * w, lds, 0, acc);
-    if (l == 4) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+    if (l == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
     __syncthreads();
     epilogue_mul_dact(lds, acc, scratch + (size_t)(l - 1) * kScratchLayerF4);
     __syncthreads();
   }
-  gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
+  if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
   float n[kSets][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  if (w == 0) pe_jacobian_t<0>(lds, accpe, n); else pe_jacobian_t<1>(lds, accpe, n);
+  if (w == 0) pe_jacobian_t<0>(lds, accpe, n); else if (w == 1) pe_jacobian_t<1>(lds, accpe, n);
 #pragma unroll
   for (int s = 0; s < kSets; ++s)
 #pragma unroll
     for (int c = 0; c < 3; ++c) n[s][c] += __shfl_xor(n[s][c], 32);
-  if (lane < 32) {
+  if (lane < 32 && w < 2) {
 #pragma unroll
     for (int s = 0; s < kSets; ++s)
 #pragma unroll

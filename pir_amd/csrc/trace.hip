@@ -59,7 +59,7 @@ __global__ void trace_init_kernel(long N, const float* __restrict__ ray_o, const
 }
 
 // One sphere-tracing evaluation (reference loop body, raytracer.py:142-156): eval `it` of 0..max_iters.
-__global__ void __launch_bounds__(kThreads, 1)
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* __restrict__ ray_d,
                   const float* __restrict__ max_dis, const unsigned char* __restrict__ work_mask,
                   float* __restrict__ pts, float* __restrict__ sdf, float* __restrict__ dis,
@@ -70,8 +70,9 @@ trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* _
   int* __restrict__ lout = it == max_iters ? ws.slist : ws.list[(it + 1) & 1];
   int* cout = ws.counters + it + 1;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
+  if (count > 2 * pk.num_cus * kWgPts) stagger_start(pk.num_cus);
   for (int base = blockIdx.x * kWgPts; base < count; base += gridDim.x * kWgPts) {
-    const int e = base + 32 * w + j;
+    const int e = base + 32 * (w & 1) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (e < count) {
       const int r = lin[e];
@@ -114,7 +115,7 @@ __device__ __forceinline__ float linspace01(int i, int n) {
 
 // Dense sampler (raytracer.py:77-100, :172-211): one workgroup per unfinished ray, 64 samples per pass,
 // stops after the pass that holds the first negative sample (later samples cannot change the result).
-__global__ void __launch_bounds__(kThreads, 1)
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 sampler_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nchunks, const float* __restrict__ ray_o,
                const float* __restrict__ ray_d, const float* __restrict__ min_dis, const float* __restrict__ max_dis,
                float* __restrict__ pts, float* __restrict__ sdf, float* __restrict__ dis,
@@ -124,6 +125,7 @@ sampler_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nchunks,
   __shared__ int s_found;
   const int count = ws.counters[max_iters + 1];
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
+  if (count > 2 * pk.num_cus) stagger_start(pk.num_cus);
   for (int q = blockIdx.x; q < count; q += gridDim.x) {
     const int r = ws.slist[q];
     const float cur = sdf[r], a = dis[r];
@@ -136,7 +138,7 @@ sampler_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nchunks,
     if (threadIdx.x == 0) { s_found = -1; s_prev_last = 0.f; }
     __syncthreads();
     for (int pass = 0; pass * kWgPts < n_steps; ++pass) {
-      const int i = pass * kWgPts + 32 * w + j;
+      const int i = pass * kWgPts + 32 * (w & 1) + j;
       float x0 = 0.f, x1 = 0.f, x2 = 0.f;
       if (i < n_steps) {
         const float z = add_rn(lo, mul_rn(linspace01(i, n_steps), span));
@@ -183,7 +185,7 @@ sampler_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nchunks,
 }
 
 // One bisection round (raytracer.py:234-247) or, with `final`, the closing evaluation (:248-250).
-__global__ void __launch_bounds__(kThreads, 1)
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 bisect_kernel(SdfPacked pk, int it, int final_pass, int max_bisect, float thr, int chunk, int nchunks,
               const float* __restrict__ ray_o, const float* __restrict__ ray_d, float* __restrict__ pts,
               float* __restrict__ sdf, float* __restrict__ dis, unsigned char* __restrict__ conv, TraceWs ws) {
@@ -193,7 +195,7 @@ bisect_kernel(SdfPacked pk, int it, int final_pass, int max_bisect, float thr, i
   int* __restrict__ flag_out = ws.flags + (it + 1) * nchunks;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   for (int base = blockIdx.x * kWgPts; base < count; base += gridDim.x * kWgPts) {
-    const int e = base + 32 * w + j;
+    const int e = base + 32 * (w & 1) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     bool active = false;
     if (e < count) {
@@ -319,6 +321,7 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
+  pk.num_cus = pir_num_cus();
   if (hipMemsetAsync(ws.counters, 0, sizeof(int) * kNumCounters + sizeof(int) * (size_t)(max_bisect + 2) * nchunks,
                      stream) != hipSuccess)
     return PIR_ERR_LAUNCH;

@@ -162,9 +162,10 @@ struct GradOut { float* w[9]; float* b[9]; };
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                     const float* __restrict__ row0_partial, GradOut out) {
-  const int job_id = blockIdx.x;
-  if (job_id == jobs.n) {   // the row-0 block
-    for (int col = threadIdx.x; col < 257; col += 256) {
+  constexpr int kParts = 16;   // blocks per C tile (1024 elements each)
+  const int job_id = blockIdx.x / kParts, part = blockIdx.x % kParts;
+  if (job_id == jobs.n) {   // the row-0 blocks: 257 columns over kParts blocks
+    for (int col = part * 256 + threadIdx.x; col < 257; col += kParts * 256) {
       float s = 0.f;
       for (int b = 0; b < kRow0Blocks; ++b) s += row0_partial[b * 257 + col];
       if (col < 256) out.w[8][col] += s; else out.b[8][0] += s;
@@ -174,14 +175,14 @@ wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, co
   const WgJob jb = jobs.j[job_id];
   const size_t stride = (size_t)jobs.n * kWgTile * kWgTile;
   const float* base = slabs + (size_t)job_id * kWgTile * kWgTile;
-  for (int e = threadIdx.x; e < kWgTile * kWgTile; e += 256) {
+  for (int e = part * (kWgTile * kWgTile / kParts) + threadIdx.x; e < (part + 1) * (kWgTile * kWgTile / kParts); e += 256) {
     const int o = jb.o0 + e / kWgTile, i = jb.i0 + e % kWgTile;
     if (o >= jb.rows || i >= jb.cols) continue;
     float s = 0.f;
     for (int k = 0; k < ksplit; ++k) s += base[k * stride + e];
     out.w[jb.layer][(size_t)(jb.row_off + o) * jb.cols + i] += jb.scale * s;
   }
-  if (jb.bias && threadIdx.x < kWgTile) {
+  if (jb.bias && part == 0 && threadIdx.x < kWgTile) {
     const int o = jb.o0 + threadIdx.x;
     if (o < jb.rows) {
       float s = 0.f;
@@ -278,7 +279,7 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
     }
     hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
                        g_sdf ? g_sdf + base : nullptr, n, row0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(jobs.n + 1), dim3(256), 0, stream, jobs, ksplit, slabs, bias_slabs,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((jobs.n + 1) * 16), dim3(256), 0, stream, jobs, ksplit, slabs, bias_slabs,
                        row0, out);
     rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
