@@ -105,7 +105,6 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
   __shared__ Lds lds;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   const int ntiles = (chunk_n + kTilePts - 1) / kTilePts;
-  if (ntiles > 2 * pk.num_cus) stagger_start(pk.num_cus);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     // Launder the lane half so that hipcc does not hoist the hundreds of per-(layer, tile, group) scratch
     // addresses out of this loop (they would all spill).
@@ -126,11 +125,14 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     __syncthreads();
 
     f32x16 acc[kSets][kTPW];
+    f32x4 pre[kTPW];
+    load_first_block<kTPW>(pk.mats, kFwd[0], kTPW * w, pre);
     // ------------------------------------------------------------------ FT sweep: activations + tangents
 #pragma nounroll
     for (int l = 0; l < 8; ++l) {
       zero_acc(acc);
-      gemm_phase<kTPW>(pk.mats, kFwd[l], kTPW * w, lds, l == 0 ? kActKB : 0, acc);
+      gemm_phase_pre<kTPW, false, true>(pk.mats, kFwd[l], kTPW * w, lds, l == 0 ? kActKB : 0, acc, pre, true,
+                                        l < 7 ? kFwd[l + 1] : kRev[7]);
       __syncthreads();
       const float* bias = pk.vecs + kVecBias + 256 * l;
 #pragma unroll
@@ -216,7 +218,7 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       __syncthreads();
       if (m >= 1) {
         zero_acc(acc);
-        gemm_phase<kTPW>(pk.mats, kRev[m], kTPW * w, lds, 0, acc);
+        gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[m], kTPW * w, lds, 0, acc, pre, m >= 2, kRev[m >= 2 ? m - 1 : m]);
         if (m == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
       } else {
         if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
@@ -256,7 +258,6 @@ extern "C" int pir_internal_bwd_sweep(const void* packed, const float* x, const 
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
-  pk.num_cus = pir_num_cus();
   const int ntiles = (chunk_n + kTilePts - 1) / kTilePts;
   const int resident = 2 * pir_num_cus();
   const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);

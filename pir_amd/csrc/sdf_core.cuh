@@ -73,23 +73,8 @@ constexpr int kVecFloats = 10 * 256 + 4;
 struct SdfPacked {
   const f32x4* mats;   // kPackedF4 entries
   const float* vecs;   // kVecFloats entries: bias of lin0..lin7, b8[1..256], w8 row 0, b8[0]
-  int num_cus;         // CUs of the device (for the start stagger below)
 };
 
-// The two workgroups that share a CU run the same program on the same amount of work, so they stay in lockstep:
-// both are in their (VALU) epilogues at the same time and the matrix pipe idles.  Delaying the second workgroup
-// of each CU by about half a layer period lets one workgroup's epilogue run under the other's MFMAs.  Which
-// blocks share a CU is not defined by HIP; blocks [num_cus, 2 num_cus) are the observed second residents -- a
-// wrong guess only loses the overlap, never correctness.
-__device__ __forceinline__ void stagger_start(int num_cus) {
-#ifndef PIR_NO_STAGGER
-  const int b = blockIdx.x;
-  if (b >= num_cus && b < 2 * num_cus) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-#endif
-}
 
 // ---- feature <-> (k-step, half) maps ---------------------------------------------------------
 // C/D layout of the 32x32 MFMA: lane = 32*h + point, register r holds tile row (r&3) + 8*(r>>2) + 4*h.
@@ -134,10 +119,21 @@ __device__ __forceinline__ void mfma_block(const f32x4 (&w)[NT], const f32x4 (&b
 // Software pipeline: the operands of k-block kb+1 (weights from L2, activations from LDS) are issued
 // before the 8*NT MFMAs of k-block kb; sched_barrier pins that order (hipcc otherwise sinks the loads
 // below the MFMAs and waits vmcnt(0) on them at once).
+// PRE: the first weight block is already in `pre` (loaded by the previous phase, so its L2 latency hid under
+// that phase's epilogue and barriers); on return `pre` holds the first block of product `next` if
+// `prefetch_next` (a wave-uniform flag).
 // ONLY1: multiply operand set 1 only (set 0's accumulators are left untouched).
-template <int NT, bool ONLY1 = false>
-__device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod p, int tile0, const Lds& lds,
-                                           int lds_kb0, f32x16 (&acc)[kSets][NT]) {
+template <int NT>
+__device__ __forceinline__ void load_first_block(const f32x4* __restrict__ mats, Prod p, int tile0, f32x4 (&pre)[NT]) {
+  const f32x4* w = mats + p.off + (size_t)tile0 * kTileKB + lane_id();
+#pragma unroll
+  for (int t = 0; t < NT; ++t) pre[t] = w[t * kTileKB];
+}
+
+template <int NT, bool ONLY1 = false, bool PRE = false>
+__device__ __forceinline__ void gemm_phase_pre(const f32x4* __restrict__ mats, Prod p, int tile0, const Lds& lds,
+                                               int lds_kb0, f32x16 (&acc)[kSets][NT], f32x4 (&pre)[NT],
+                                               bool prefetch_next, Prod next) {
   const int lane = lane_id();
   const f32x4* w = mats + p.off + (size_t)tile0 * kTileKB + lane;
   int kb_stride = p.ntiles * kTileKB;
@@ -148,7 +144,7 @@ __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod 
 #endif
   f32x4 wa[NT], wb[NT], ba[kSets], bb[kSets];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wa[t] = w[t * kTileKB];
+  for (int t = 0; t < NT; ++t) wa[t] = PRE ? pre[t] : w[t * kTileKB];
   ba[0] = lds.act[0][lds_kb0][lane];
   ba[1] = lds.act[1][lds_kb0][lane];
   int kb = 0;
@@ -172,11 +168,19 @@ __device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod 
       ba[0] = lds.act[0][lds_kb0 + k2][lane];
       ba[1] = lds.act[1][lds_kb0 + k2][lane];
     }
+    if (prefetch_next && kb + 2 >= last) load_first_block<NT>(mats, next, tile0, pre);
     __builtin_amdgcn_sched_barrier(0);
     mfma_block<NT, ONLY1>(wb, bb, acc);
     __builtin_amdgcn_sched_barrier(0);
   }
   if (kb == last) mfma_block<NT, ONLY1>(wa, ba, acc);
+}
+
+template <int NT, bool ONLY1 = false>
+__device__ __forceinline__ void gemm_phase(const f32x4* __restrict__ mats, Prod p, int tile0, const Lds& lds,
+                                           int lds_kb0, f32x16 (&acc)[kSets][NT]) {
+  f32x4 pre[NT];
+  gemm_phase_pre<NT, ONLY1, false>(mats, p, tile0, lds, lds_kb0, acc, pre, false, p);
 }
 
 template <int NT>

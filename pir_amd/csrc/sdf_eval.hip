@@ -92,7 +92,6 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   const long ntiles = (M + kWgPts - 1) / kWgPts;
   f32x4* scratch = kNormal ? scratch_all + (size_t)blockIdx.x * kScratchWgF4 : nullptr;
-  stagger_start(pk.num_cus);
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long base = tile * kWgPts;
     const long P = base + 32 * (w & 1) + j;
@@ -174,7 +173,6 @@ static SdfPacked make_packed(const void* packed) {
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
-  pk.num_cus = pir_num_cus();
   return pk;
 }
 

@@ -23,11 +23,13 @@ __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, fl
   if (w < kSets) write_pe(lds, w, x0, x1, x2);   // wave w encodes the points of set w
   __syncthreads();
   f32x16 acc[kSets][kTPW];
+  f32x4 pre[kTPW];
+  load_first_block<kTPW>(pk.mats, kFwd[0], kTPW * w, pre);
 #pragma nounroll
   for (int l = 0; l < 8; ++l) {
     zero_acc(acc);
     const Prod p = kFwd[l];
-    gemm_phase<kTPW>(pk.mats, p, kTPW * w, lds, l == 0 ? kActKB : 0, acc);
+    gemm_phase_pre<kTPW, false, true>(pk.mats, p, kTPW * w, lds, l == 0 ? kActKB : 0, acc, pre, l < 7, kFwd[l < 7 ? l + 1 : l]);
     __syncthreads();   // every read of the previous activations is done
     epilogue_softplus<STORE>(lds, acc, pk.vecs + kVecBias + 256 * l, scratch + (size_t)l * kScratchLayerF4);
     __syncthreads();
@@ -177,10 +179,12 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
   f32x16 acc[kSets][kTPW];
   f32x16 accpe[kSets][1];
   zero_acc(accpe);
+  f32x4 pre[kTPW];
+  load_first_block<kTPW>(pk.mats, kRev[7], kTPW * w, pre);
 #pragma nounroll
   for (int l = 7; l >= 1; --l) {
     zero_acc(acc);
-    gemm_phase<kTPW>(pk.mats, kRev[l], kTPW * w, lds, 0, acc);
+    gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[l], kTPW * w, lds, 0, acc, pre, l >= 2, kRev[l >= 2 ? l - 1 : l]);
     if (l == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
     __syncthreads();
     epilogue_mul_dact(lds, acc, scratch + (size_t)(l - 1) * kScratchLayerF4);

@@ -70,7 +70,6 @@ trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* _
   int* __restrict__ lout = it == max_iters ? ws.slist : ws.list[(it + 1) & 1];
   int* cout = ws.counters + it + 1;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
-  if (count > 2 * pk.num_cus * kWgPts) stagger_start(pk.num_cus);
   for (int base = blockIdx.x * kWgPts; base < count; base += gridDim.x * kWgPts) {
     const int e = base + 32 * (w & 1) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
@@ -125,7 +124,6 @@ sampler_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nchunks,
   __shared__ int s_found;
   const int count = ws.counters[max_iters + 1];
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
-  if (count > 2 * pk.num_cus) stagger_start(pk.num_cus);
   for (int q = blockIdx.x; q < count; q += gridDim.x) {
     const int r = ws.slist[q];
     const float cur = sdf[r], a = dis[r];
@@ -321,7 +319,6 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
-  pk.num_cus = pir_num_cus();
   if (hipMemsetAsync(ws.counters, 0, sizeof(int) * kNumCounters + sizeof(int) * (size_t)(max_bisect + 2) * nchunks,
                      stream) != hipSuccess)
     return PIR_ERR_LAUNCH;
