@@ -161,6 +161,16 @@ def main():
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
                     "launches": int(launches[dom]), "avg_launch_ms": round(total_ms[dom] / launches[dom], 4),
                     "flop_per_point": alg[dom], "points_per_launch": round(units[dom] / launches[dom], 1)}
+    # HBM traffic of the dominant kernel: bytes/point from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is; tools/kprof.py is the profiled program),
+    # scaled to this run's points per launch.  None when no PMC pass exists for that kernel.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if roofline and names[dom] in pmc:
+            roofline["traffic"] = round(pmc[names[dom]]["hbm_bytes_per_point"] * units[dom] / launches[dom])
+            roofline["traffic_unit"] = "bytes/launch (PMC bytes/point x points/launch)"
+    except (OSError, ValueError, KeyError):
+        pass
     breakdown = {names[i]: {"launches": int(launches[i]), "ms_per_step": round(total_ms[i] / args.steps, 3)}
                  for i in range(nk) if launches[i]}
 

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (not the headline bench line):
+  config 1: 256x256 forward render, collocated light, no training       (rays/s)
+  config 2: 800x800 trace + shade fwd+bwd, collocated (no shadow rays)   (rays/s)
+  config 3: 800x800 visibility bake, 256 samples, forward only           (rays/s)
+  config 5: 2048x2048 view, L lights: visibility(128, fwd) + shade(fwd)  (ray-light pairs/s)
+"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pir_amd import scene
+from pir_amd.render_fn import make_render_fn
+from pir_amd.renderer.raytracer import (RayTracer, render_camera, render_camera_visibility, raytrace_camera,
+                                        render_light_visibility, render_normal_and_color)
+from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+
+
+def timed(fn, n=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    sdf, mats, dino = scene.build_networks(0, dev)
+    tracer = RayTracer()
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    inv_s = torch.full((1, 1), scene.INV_S, device=dev)
+    pl = mats["point_light_network"]
+    out = []
+    cam = scene.make_camera(256, 256, device=dev)
+    with torch.no_grad():
+        t = timed(lambda: render_camera(cam, sdf, tracer, mats, dino, render_fn, fill_holes=False, handle_edges=False,
+                                        indirect_warmup=True, is_training=False))
+    out.append({"config": 1, "what": "256x256 forward, collocated", "rays_per_s": 256 * 256 / t, "ms": t * 1e3})
+    cam = scene.make_camera(800, 800, device=dev)
+    params = list(sdf.parameters()) + [p for k in mats for p in mats[k].parameters()]
+
+    def step2():
+        for p in params:
+            p.grad = None
+        r = render_camera(cam, sdf, tracer, mats, dino, render_fn, fill_holes=False, handle_edges=False,
+                          indirect_warmup=True, is_training=True)
+        scene.step_loss(r).backward()
+    t = timed(step2)
+    out.append({"config": 2, "what": "800x800 trace + shade fwd+bwd, collocated", "rays_per_s": 800 * 800 / t, "ms": t * 1e3})
+    with torch.no_grad():
+        lp = cam.get_light_pos(pl.offset)
+        t = timed(lambda: render_camera_visibility(cam, sdf, tracer, fill_holes=False, handle_edges=False,
+                                                   is_training=False, inv_s=inv_s, render_visibility=True,
+                                                   max_num_pts=2500, light_pos=lp))
+    out.append({"config": 3, "what": "800x800 visibility bake (256 samples), forward", "rays_per_s": 800 * 800 / t, "ms": t * 1e3})
+    cam = scene.make_camera(2048, 2048, device=dev)
+    n_l = 4
+    import math
+    lights = []
+    for i in range(n_l):   # Fibonacci sphere, radius 3
+        z = 1 - 2 * (i + 0.5) / n_l
+        r = math.sqrt(1 - z * z)
+        a = math.pi * (1 + 5 ** 0.5) * i
+        lights.append(torch.tensor([[3 * r * math.cos(a), 3 * r * math.sin(a), 3 * z]], device=dev))
+
+    def relight():
+        with torch.no_grad():
+            res = raytrace_camera(cam, sdf, tracer)
+            for lp in lights:
+                render_light_visibility(res, cam, lp, sdf, inv_s, n_samples=128, is_training=False)
+                render_normal_and_color(res, sdf, mats, dino, render_fn, is_training=False, light_pos=lp)
+    t = timed(relight, n=1, warm=1)
+    out.append({"config": 5, "what": f"2048x2048 view, {n_l} lights: trace once + per light visibility(128)+shade, forward",
+                "ray_light_pairs_per_s": 2048 * 2048 * n_l / t, "ms": t * 1e3})
+    for o in out:
+        print(json.dumps(o))
+
+
+if __name__ == "__main__":
+    main()
