@@ -143,6 +143,12 @@ class CameraRays:
         """:297-303 -- camera-frame offset -> world position."""
         return offset @ self.C2W[:3, :3].t() + self.C2W[:3, 3].unsqueeze(0)
 
+    def project(self, points: Tensor) -> Tensor:
+        """:340-356 -- world points -> (u, v)."""
+        p = torch.cat([points.reshape(-1, 3), torch.ones(points.numel() // 3, 1)], dim=1)
+        q = (p @ self.W2C.t()) @ self.K.t()
+        return (q[:, :2] / q[:, 2:3]).reshape(list(points.shape[:-1]) + [2])
+
 
 def intersect_sphere(ray_o: Tensor, ray_d: Tensor, r: float = 1.0):
     """src/renderer/raytracer.py:253-273."""
@@ -495,3 +501,209 @@ def step_loss(res: Dict[str, Tensor]) -> Tensor:
         color = color * res["vis"][..., None]
     m = res["convergent_mask"]
     return color.sum() + ((res["normal"][m].norm(dim=-1) - 1.0) ** 2).sum()
+
+
+# ----------------------------------------------------------------------------
+# Next rows: IRON edge sampling and one-bounce indirect lighting
+# ----------------------------------------------------------------------------
+
+
+def sobel_magnitude(depth: Tensor) -> Tensor:
+    """kornia.filters.sobel(depth[None, None]) as raytrace_camera calls it (src/renderer/raytracer.py:645).
+
+    kornia is a third-party dependency that is absent here and unpinned in the reference (README.md:46);
+    this restates its published algorithm: 3x3 Sobel kernels normalised by 8, replicate padding,
+    sqrt(gx^2 + gy^2 + 1e-6).  PARITY UNPINNED for this function (no kornia output to compare with).
+    """
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+    x = torch.nn.functional.pad(depth[None, None], (1, 1, 1, 1), mode="replicate")
+    g = torch.nn.functional.conv2d(x, torch.stack([kx, kx.t()])[:, None])[0]
+    return torch.sqrt(g[0] * g[0] + g[1] * g[1] + 1e-6)
+
+
+def raytrace_uv(cam: CameraRays, layers, tracer: Tracer, uv: Tensor, **kw) -> Dict[str, Tensor]:
+    """raytrace_pixels for an arbitrary list of pixel positions (src/renderer/raytracer.py:405-484)."""
+    ray_o, ray_d, ray_n = cam.rays(uv)
+    sdf = lambda x: sdf_forward(layers, x, **kw)[..., 0]  # noqa: E731
+    hit, lo, hi = intersect_sphere(ray_o, ray_d, 1.0)
+    with torch.no_grad():
+        res = tracer.trace(sdf, ray_o, ray_d, lo, hi, hit)
+    res["depth"] = res["distance"] / ray_n
+    res.update(uv=uv, ray_o=ray_o, ray_d=ray_d, ray_d_norm=ray_n)
+    return res
+
+
+def first_occurrence_unique(x: Tensor) -> Tuple[Tensor, Tensor]:
+    """`unique` (src/renderer/raytracer.py:487-494): sorted unique values and, for each, the index of its first
+    occurrence in x (the reference gets it from a scatter of the flipped index range, last write wins)."""
+    vals, inv = torch.unique(x, return_inverse=True)
+    first = torch.full((vals.shape[0],), x.shape[0], dtype=torch.long)
+    for i in range(x.shape[0] - 1, -1, -1):
+        first[inv[i]] = i
+    return vals, first
+
+
+@torch.no_grad()
+def locate_edge_points(cam: CameraRays, start_points: Tensor, layers, mask: Tensor, max_step: int = 16,
+                       step_size: float = 1e-3, dot_threshold: float = 5e-2, **kw) -> Dict[str, Tensor]:
+    """Surface walk towards the silhouette (src/renderer/raytracer.py:497-589)."""
+    cam_o = cam.C2W[:3, 3]
+    pts = start_points[mask].reshape(-1, 3).clone()
+    found = torch.zeros(pts.shape[0], dtype=torch.bool)
+    if pts.shape[0] > 0:
+        for it in range(max_step + 1):
+            todo = ~found
+            view = cam_o - pts[todo]
+            view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
+            sdf, _, nrm = sdf_get_all(layers, pts[todo], is_training=False, **kw)
+            nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-10)
+            dot = (nrm * view).sum(-1)
+            keep_walking = dot.abs() > dot_threshold                      # :531
+            found[todo] = ~keep_walking
+            if it >= max_step or not (~found).any():
+                break
+            walk = nrm - view / dot.unsqueeze(-1)                          # :538
+            walk = walk / (walk.norm(dim=-1, keepdim=True) + 1e-10)
+            walk = walk - sdf * nrm                                        # :541
+            idx = todo.nonzero()[:, 0][keep_walking]
+            pts[idx] += (step_size * walk)[keep_walking]
+    edge_points = pts[found]
+    edge_mask = torch.zeros(cam.H, cam.W, dtype=torch.bool)
+    edge_uv = torch.zeros(edge_points.shape[0], 2)
+    pix = torch.zeros(0, dtype=torch.long)
+    if found.any():
+        edge_uv = cam.project(edge_points)
+        ij = torch.floor(edge_uv).long()
+        pix = ij[:, 1] * cam.W + ij[:, 0]
+        ok = (pix < cam.H * cam.W) & (pix >= 0)                            # :569
+        pix, edge_points, edge_uv = pix[ok], edge_points[ok], edge_uv[ok]
+        if ok.any():
+            pix, first = first_occurrence_unique(pix)
+            edge_points, edge_uv = edge_points[first], edge_uv[first]
+            edge_mask.view(-1)[pix] = True
+    return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": pix}
+
+
+def blend_mlp(layers, cfg: dict, distance: Tensor, roughness: Tensor, dot_n_wo: Tensor) -> Tensor:
+    """BlendNetwork.forward (src/network.py:344-367), no skip connections, no extra features."""
+    h = torch.cat([distance, roughness, posenc(dot_n_wo, cfg.get("multires_view", 8))], dim=-1)
+    n = len(layers)
+    for l, (w, b) in enumerate(layers):
+        h = h @ w.t() + b
+        if l < n - 1:
+            h = torch.relu(h)
+    h = cfg.get("output_scale", 1.0) * (h + cfg.get("output_bias", 0.0))
+    if cfg.get("squeeze_out", True):
+        return cfg.get("squeeze_out_scale", 1.0) * torch.sigmoid(h)
+    return torch.relu(h) * 2.0 * np.pi
+
+
+def shade_traced(res: Dict[str, Tensor], sdf_layers, mats, dino, tables, light, *, light_pos: Optional[Tensor],
+                 is_training: bool) -> Dict[str, Tensor]:
+    """render_normal_and_color on a flat list of traced rays (src/renderer/raytracer.py:780-865)."""
+    mask = res["convergent_mask"].reshape(-1)
+    if not mask.any():
+        return render_fn(mask, mats, tables, None, None, None, None, None, None, light)
+    pts = res["points"].reshape(-1, 3)[mask]
+    ray_d = res["ray_d"].reshape(-1, 3)[mask]
+    ray_o = res["ray_o"].reshape(-1, 3)[mask]
+    sdf, feat, nrm = sdf_get_all(sdf_layers, pts, is_training=is_training)
+    dino_f = dino_mlp(dino["layers"], dino["cfg"], pts).detach()
+    p = reparam_points(pts, nrm.detach(), -ray_d.detach(), sdf) if is_training else pts
+    lightdir = distance = None
+    with torch.set_grad_enabled(is_training):
+        if light_pos is not None:
+            lightdir = torch.nn.functional.normalize(p - light_pos, eps=1e-10)
+            distance = (p - light_pos).norm(dim=-1, keepdim=True)
+        out = render_fn(mask, mats, tables, ray_o, ray_d, p, nrm, feat, dino_f, light, lightdir, distance)
+    out["dino_feature"] = torch.zeros(mask.shape[0], dino_f.shape[-1]).index_put((mask.nonzero()[:, 0],), dino_f)
+    return out
+
+
+def render_indirect(res: Dict[str, Tensor], sdf_layers, mats, dino, tables, tracer: Tracer, light, *,
+                    is_training: bool) -> Tuple[Tensor, Tensor]:
+    """render_indirect_lighting as render_camera calls it: light_pos=None, sec_is_training=False, diff_geo=True
+    (src/renderer/raytracer.py:1003-1189).  Returns (indirect_color [H,W,3], indirect_blend_coef [H,W,1])."""
+    H, W = res["convergent_mask"].shape
+    pmask = res["convergent_mask"].reshape(-1)
+    color = torch.zeros(H * W, 3)
+    coef = torch.ones(H * W)
+    if pmask.any():
+        pts = res["points"].reshape(-1, 3)[pmask].clone()
+        ray_o = res["ray_o"].reshape(-1, 3)[pmask]
+        ray_d = res["ray_d"].reshape(-1, 3)[pmask]
+        nrm = sdf_get_all(sdf_layers, pts, is_training=False)[2]
+        nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-10)
+        wo = (-ray_d * nrm).sum(-1, keepdim=True) * nrm * 2 + ray_d         # mirror direction, :1041
+        wo = wo / (wo.norm(dim=-1, keepdim=True) + 1e-10)
+        sdf = lambda x: sdf_forward(sdf_layers, x)[:, 0]  # noqa: E731
+        with torch.no_grad():
+            hit, lo, hi = intersect_sphere(pts, wo, 1.0)
+            sec = tracer.trace(sdf, pts, wo, lo.clamp(0.001, 3.0), hi.clamp(0.001, 3.0), hit)
+        m2 = sec["convergent_mask"]
+        hit_pts = sec["points"][m2]
+        # secondary shading, no gradients (:1075-1112): light at the camera, radiance falls off with distance^2
+        ldir = hit_pts - ray_o[m2]
+        hdist = ldir.norm(dim=-1, keepdim=True)
+        ldir = ldir / (ldir.norm(dim=-1, keepdim=True) + 1e-10)
+        h_sdf, h_feat, h_nrm = sdf_get_all(sdf_layers, hit_pts, is_training=False)
+        h_dino = dino_mlp(dino["layers"], dino["cfg"], hit_pts).detach()
+        with torch.no_grad():
+            sec_out = render_fn(m2, mats, tables, pts[m2], wo[m2], hit_pts, h_nrm, h_feat, h_dino, light,
+                                lightdir=ldir, distance=hdist, direct_radiance=True)
+        radiance = sec_out["color"][m2]
+        # primary shading lit by the secondary radiance from -wo (:1116-1144)
+        p1, o1, d1, w1 = pts[m2], ray_o[m2], ray_d[m2], wo[m2]
+        p_sdf, p_feat, p_nrm = sdf_get_all(sdf_layers, p1, is_training=is_training)
+        p_dino = dino_mlp(dino["layers"], dino["cfg"], p1).detach()
+        if is_training:
+            p1 = reparam_points(p1, p_nrm.detach(), -d1.detach(), p_sdf)
+        with torch.set_grad_enabled(is_training):
+            out = render_fn(m2, mats, tables, o1, d1, p1, p_nrm, p_feat, p_dino, radiance, lightdir=-w1,
+                            distance=None, direct_radiance=False)
+            blend = torch.ones(m2.shape[0])
+            if m2.any():
+                rough = out["specular_roughness"][m2].reshape(-1, 1).detach()
+                n1 = p_nrm.detach()
+                n1 = n1 / (n1.norm(dim=-1, keepdim=True) + 1e-10)
+                dot = (w1 * n1).sum(-1, keepdim=True)
+                dist = (p1 - hit_pts).norm(dim=-1, keepdim=True)
+                b = blend_mlp(mats["blend_network"]["layers"], mats["blend_network"]["cfg"], dist, rough, dot)
+                blend = blend.index_put((m2.nonzero()[:, 0],), b.squeeze(-1))
+        idx = pmask.nonzero()[:, 0]
+        color = color.index_put((idx,), out["color"])
+        coef = coef.index_put((idx,), blend)
+    return color.reshape(H, W, 3), coef.reshape(H, W, 1)
+
+
+def render_edge_pixels(res: Dict[str, Tensor], cam: CameraRays, sdf_layers, mats, dino, tables, tracer: Tracer,
+                       light, *, light_pos: Optional[Tensor], is_training: bool) -> None:
+    """Edge pixels = area-weighted mix of the colours either side of the silhouette
+    (src/renderer/raytracer.py:872-951).  Updates color / normal / uv / points of `res` in place."""
+    H, W = res["edge_mask"].shape
+    e_pts, e_uv, e_idx = res["edge_points"], res["edge_uv"], res["edge_pixel_idx"]
+    centre = torch.floor(e_uv) + 0.5
+    e_sdf, _, e_grad = sdf_get_all(sdf_layers, e_pts, is_training=is_training)
+    e_n = e_grad.detach() / (e_grad.detach().norm(dim=-1, keepdim=True) + 1e-10)
+    if is_training:
+        e_pts = reparam_points(e_pts, e_grad.detach(), e_n, e_sdf)
+        e_uv = cam.project(e_pts)
+    n2d = (e_n @ cam.W2C[:3, :3].t())[:, :2]
+    n2d = n2d / (n2d.norm(dim=-1, keepdim=True) + 1e-10)
+    radius = 0.707
+    dot2d = ((e_uv - centre) * n2d).sum(-1)
+    alpha = 2 * torch.arccos((dot2d / radius).clamp(0.0, 1.0))
+    w_pos = (1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)).unsqueeze(-1)
+    sides = []
+    for sign in (-1.0, 1.0):                                                # positive side first (:905-906)
+        tr = raytrace_uv(cam, sdf_layers, tracer, centre + sign * radius * n2d)
+        sides.append((tr, shade_traced(tr, sdf_layers, mats, dino, tables, light, light_pos=light_pos,
+                                       is_training=is_training)))
+    (tr_p, pos), (tr_n, neg) = sides
+    mix = lambda k: pos[k] * w_pos + neg[k] * (1.0 - w_pos)  # noqa: E731
+    res["color"] = res["color"].reshape(-1, 3).index_put((e_idx,), mix("color")).reshape(H, W, 3)
+    res["normal"] = res["normal"].reshape(-1, 3).index_put((e_idx,), e_grad).reshape(H, W, 3)
+    res["edge_pos_neg_normal"] = torch.cat([pos["normal"][tr_p["convergent_mask"]],
+                                            neg["normal"][tr_n["convergent_mask"]]], dim=0)
+    res["uv"] = res["uv"].reshape(-1, 2).index_put((e_idx,), e_uv.detach()).reshape(H, W, 2)
+    res["points"] = res["points"].reshape(-1, 3).index_put((e_idx,), e_pts.detach()).reshape(H, W, 3)

@@ -263,6 +263,46 @@ class PointLightNetwork(nn.Module):
         return self.light_offset.weight.data.detach()
 
 
+class BlendNetwork(nn.Module):
+    """Blend weight of the one-bounce indirect term from (distance, roughness, PE(n.wo))
+    (reference: src/network.py:295-367).  squeeze_out=False gives relu(x) * 2 pi."""
+
+    def __init__(self, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires_view=8, squeeze_out=True,
+                 squeeze_out_scale=1.0, output_bias=0.0, output_scale=1.0, skip_in=()):
+        super().__init__()
+        self.squeeze_out = squeeze_out
+        dims = [d_in] + [d_hidden] * n_layers + [d_out]
+        self.embedview_fn = None
+        if multires_view > 0:
+            self.embedview_fn, ch = get_embedder(multires_view, input_dims=1)
+            dims[0] += ch - 1
+        self.num_layers = len(dims)
+        self.skip_in = tuple(skip_in)
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                dims[l] += dims[0]
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            setattr(self, "lin" + str(l), WNLinear(dims[l], out_dim, weight_norm))
+        self.output_bias, self.output_scale, self.squeeze_out_scale = output_bias, output_scale, squeeze_out_scale
+
+    def forward(self, distance, roughness, dot_n_wo, features=None):
+        if self.embedview_fn is not None:
+            dot_n_wo = self.embedview_fn(dot_n_wo)
+        inp = torch.cat([distance, roughness, dot_n_wo] + ([features] if features is not None else []), dim=-1)
+        x = inp
+        for l in range(self.num_layers - 1):
+            if l in self.skip_in:
+                x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
+            x = getattr(self, "lin" + str(l))(x)
+            if l < self.num_layers - 2:
+                x = F.relu(x)
+        x = self.output_scale * (x + self.output_bias)
+        if self.squeeze_out:
+            return self.squeeze_out_scale * torch.sigmoid(x)
+        return F.relu(x) * 2.0 * np.pi
+
+
 class SingleVarianceNetwork(nn.Module):
     """inv_s = exp(10 * variance) (reference: src/network.py:370-379)."""
 

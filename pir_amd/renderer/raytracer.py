@@ -307,10 +307,77 @@ def _closing3x3(depth):
     return x[0, 0]
 
 
+def _sobel_magnitude(depth):
+    """kornia.filters.sobel without kornia: 3x3 Sobel kernels normalised by 8, replicate padding,
+    sqrt(gx^2 + gy^2 + 1e-6) (kornia's published algorithm; parity with kornia itself unpinned)."""
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=depth.device) / 8.0
+    x = F.pad(depth[None, None], (1, 1, 1, 1), mode="replicate")
+    g = F.conv2d(x, torch.stack([kx, kx.t()])[:, None])[0]
+    return torch.sqrt(g[0] * g[0] + g[1] * g[1] + 1e-6)
+
+
+def unique(x, dim=-1):
+    """Sorted unique values of x and the index of the first occurrence of each (raytracer.py:487-494).  The
+    reference scatters a flipped index range and relies on the last write winning, which only holds on the CPU;
+    an `amin` scatter-reduce gives the same answer deterministically on the GPU."""
+    vals, inverse = torch.unique(x, return_inverse=True, dim=dim)
+    perm = torch.arange(inverse.size(dim), dtype=inverse.dtype, device=inverse.device)
+    first = torch.full((vals.size(dim),), inverse.size(dim), dtype=inverse.dtype, device=inverse.device)
+    return vals, first.scatter_reduce_(0, inverse, perm, reduce="amin")
+
+
+@torch.no_grad()
+def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_size, dot_threshold,
+                       max_num_rays=200000, mask=None):
+    """Walk on the surface from the depth-edge pixels until the normal is perpendicular to the view direction
+    (raytracer.py:497-615) -> dict(edge_mask [H,W], edge_points [E,3], edge_uv [E,2], edge_pixel_idx [E]).
+    Every step is one `get_all` over the points still walking, i.e. one launch of the fused HIP kernel."""
+    if mask is None:
+        mask = torch.ones_like(walk_start_points[..., 0]).bool()
+    dev = walk_start_points.device
+    cam_o = camera.get_camera_origin()
+    pts = walk_start_points[mask].reshape(-1, 3).detach().clone()
+    found = torch.zeros(pts.shape[0], dtype=torch.bool, device=dev)
+    for s in range(0, pts.shape[0], max_num_rays):       # the reference walks max_num_rays points at a time
+        cur, cur_found = pts[s:s + max_num_rays], found[s:s + max_num_rays]
+        todo = torch.arange(cur.shape[0], device=dev)    # indices of the points still walking
+        for it in range(max_step + 1):
+            x = cur[todo]
+            view = cam_o - x
+            view = view / (view.norm(dim=-1, keepdim=True) + 1e-10)
+            sdf, _, nrm = sdf_network.get_all(x.clone(), is_training=False)
+            nrm = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-10)
+            dot = (nrm * view).sum(dim=-1)
+            walking = dot.abs() > dot_threshold
+            cur_found[todo[~walking]] = True
+            if it >= max_step or not bool(walking.any()):
+                break
+            step = nrm - view / dot.unsqueeze(-1)
+            step = step / (step.norm(dim=-1, keepdim=True) + 1e-10)
+            step = step - sdf.reshape(-1, 1) * nrm       # stay near the zero level set
+            todo = todo[walking]
+            cur[todo] += (step_size * step)[walking]
+    edge_points = pts[found]
+    edge_mask = torch.zeros(camera.H, camera.W, dtype=torch.bool, device=dev)
+    edge_uv = torch.zeros_like(edge_points[..., :2])
+    update_pixels = torch.zeros(0, dtype=torch.long, device=dev)
+    if edge_points.shape[0] > 0:
+        edge_uv = camera.project(edge_points)
+        pix = torch.floor(edge_uv).long()
+        update_pixels = pix[:, 1] * camera.W + pix[:, 0]
+        ok = (update_pixels < camera.H * camera.W) & (update_pixels >= 0)
+        update_pixels, edge_points, edge_uv = update_pixels[ok], edge_points[ok], edge_uv[ok]
+        if update_pixels.shape[0] > 0:
+            update_pixels, first = unique(update_pixels, dim=0)   # one edge point per pixel: the first found
+            edge_points, edge_uv = edge_points[first], edge_uv[first]
+            edge_mask.view(-1)[update_pixels] = True
+    return {"edge_mask": edge_mask, "edge_points": edge_points, "edge_uv": edge_uv, "edge_pixel_idx": update_pixels}
+
+
 @torch.no_grad()
 def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=False, detect_edges=False):
-    """raytracer.py:618-666.  fill_holes uses a kornia-free 3x3 closing (parity with kornia unpinned, SURVEY 8c);
-    detect_edges (IRON edge sampling, raytracer.py:497-615) is not part of the accelerated path yet."""
+    """raytracer.py:618-666.  fill_holes / detect_edges use kornia-free 3x3 closing / Sobel filters (parity with
+    kornia unpinned)."""
     results = raytrace_pixels(sdf_network, raytracer, camera.get_uv(), camera, max_num_rays=max_num_rays,
                               _pixel_grid=True)
     results["depth"] = results["depth"] * results["convergent_mask"].float()
@@ -324,9 +391,12 @@ def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_ho
             results["distance"] = results["depth"] * results["ray_d_norm"]
             results["points"] = results["ray_o"] + results["ray_d"] * results["distance"].unsqueeze(-1)
     if detect_edges:
-        raise NotImplementedError("edge-aware sampling (locate_edge_points / render_edge_pixels) is outside the "
-                                  "accelerated hot path in this release; call with handle_edges=False")
-    results["edge_mask"] = torch.zeros_like(results["convergent_mask"])
+        depth_edge_mask = (_sobel_magnitude(results["depth"]) > 1e-2) & results["convergent_mask"]
+        results.update(locate_edge_points(camera, results["points"], sdf_network, max_step=16, step_size=1e-3,
+                                          dot_threshold=5e-2, max_num_rays=max_num_rays, mask=depth_edge_mask))
+        results["convergent_mask"] = results["convergent_mask"] & ~results["edge_mask"]
+    else:
+        results["edge_mask"] = torch.zeros_like(results["convergent_mask"])
     return results
 
 
@@ -407,11 +477,142 @@ def render_normal_and_color(results, sdf_network, color_network_dict, dino_netwo
         results[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
 
 
+def _put_rows(img, idx, rows):
+    """img.view(-1, C)[idx] = rows, out of place (keeps autograd history of both operands)."""
+    shp = img.shape
+    flat = img.reshape(shp[0] * shp[1], -1)
+    return flat.index_put((idx,), rows.reshape(idx.shape[0], -1)).reshape(shp)
+
+
+def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, dino_network, render_fn,
+                       is_training=False, light_pos=None, roughness_warmup=False):
+    """Colour of an edge pixel = area-weighted mix of the colours traced either side of the silhouette, with the
+    weight differentiable w.r.t. the edge point (raytracer.py:872-951)."""
+    edge_points, edge_uv, edge_pixel_idx = results["edge_points"], results["edge_uv"], results["edge_pixel_idx"]
+    centre = torch.floor(edge_uv) + 0.5
+    edge_sdf, _, edge_grads = sdf_network.get_all(edge_points, is_training=is_training)
+    g = edge_grads.detach()
+    edge_normals = g / (g.norm(dim=-1, keepdim=True) + 1e-10)
+    if is_training:
+        edge_points = reparam_points(edge_points, g, edge_normals, edge_sdf)
+        edge_uv = camera.project(edge_points)
+    n2d = torch.matmul(edge_normals, camera.W2C[:3, :3].transpose(1, 0))[:, :2]
+    n2d = n2d / (n2d.norm(dim=-1, keepdim=True) + 1e-10)
+    pixel_radius = 0.707
+    dot2d = torch.sum((edge_uv - centre) * n2d, dim=-1)
+    alpha = 2 * torch.arccos(torch.clamp(dot2d / pixel_radius, min=0.0, max=1.0))
+    w_pos = (1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)).unsqueeze(-1)
+
+    sides = []
+    for side_uv in (centre - pixel_radius * n2d, centre + pixel_radius * n2d):   # positive side, negative side
+        r = raytrace_pixels(sdf_network, raytracer, side_uv, camera)
+        render_normal_and_color(r, sdf_network, color_network_dict, dino_network, render_fn,
+                                is_training=is_training, light_pos=light_pos, roughness_warmup=roughness_warmup)
+        sides.append(r)
+    pos, neg = sides
+
+    def mix(key):
+        a, b = pos[key], neg[key]
+        w = w_pos if a.dim() == 2 else w_pos.squeeze(-1)
+        return a * w + b * (1.0 - w)
+
+    results["color"] = _put_rows(results["color"], edge_pixel_idx, mix("color"))
+    results["normal"] = _put_rows(results["normal"], edge_pixel_idx, edge_grads)
+    for key in ("diffuse_albedo", "specular_albedo", "specular_roughness", "dino_feature"):   # visualisation maps
+        results[key] = _put_rows(results[key], edge_pixel_idx, mix(key))
+    results["edge_pos_neg_normal"] = torch.cat([pos["normal"][pos["convergent_mask"]],
+                                                neg["normal"][neg["convergent_mask"]]], dim=0)
+    results["uv"] = _put_rows(results["uv"], edge_pixel_idx, edge_uv.detach())
+    results["points"] = _put_rows(results["points"], edge_pixel_idx, edge_points.detach())
+
+
+def render_indirect_lighting(results, sdf_network, color_network_dict, dino_network, raytracer, render_fn,
+                             light_pos=None, roughness_warmup=False, is_training=False, sec_is_training=False,
+                             diff_geo=True):
+    """One mirror bounce: trace the reflected ray of every hit, shade the secondary hit under the point light,
+    then shade the primary point lit by that radiance; a BlendNetwork weight per pixel
+    (raytracer.py:1003-1189).  Adds results["indirect_color"] [H,W,3] and ["indirect_blend_coef"] [H,W,1]."""
+    dots_sh = list(results["convergent_mask"].shape)
+    device = results["points"].device
+    points_mask = results["convergent_mask"].reshape(-1)
+    n_pix = points_mask.shape[0]
+    indirect_color = torch.zeros(n_pix, 3, device=device)
+    indirect_blend_coef = torch.ones(n_pix, device=device)
+    if points_mask.any():
+        all_points = results["points"].reshape(-1, 3)[points_mask].clone()
+        all_ray_o = results["ray_o"].reshape(-1, 3)[points_mask]
+        all_ray_d = results["ray_d"].reshape(-1, 3)[points_mask]
+        colors, coefs = [], []
+        sdf_fn = SdfCallable(sdf_network)
+        for points, ray_o, ray_d in zip(torch.split(all_points, 200000), torch.split(all_ray_o, 200000),
+                                        torch.split(all_ray_d, 200000)):
+            with torch.no_grad():
+                normals = sdf_network.get_all(points.clone(), is_training=False)[2]
+                normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+                sample_dirs = torch.sum(-ray_d * normals, dim=-1, keepdim=True) * normals * 2 + ray_d
+                sample_dirs = sample_dirs / (sample_dirs.norm(dim=-1, keepdim=True) + 1e-10)
+                hit, lo, hi = intersect_sphere(points, sample_dirs, r=1.0)
+                sec = raytracer(sdf_fn, points, sample_dirs, lo.clamp(min=0.001, max=3.00),
+                                hi.clamp(min=0.001, max=3.00), hit)
+                sec_mask, sec_points = sec["convergent_mask"], sec["points"]
+                if light_pos is not None:   # un-colocated light: drop secondary points that do not see the camera
+                    z = torch.linspace(0.01, 0.8, 20, device=device)
+                    dirs = ray_o[sec_mask] - sec_points[sec_mask]
+                    dirs = dirs / (dirs.norm(dim=-1, keepdim=True) + 1e-10)
+                    probe = sec_points[sec_mask][:, None, :] + dirs[:, None, :] * z[None, :, None]
+                    probe_sdf = sdf_fn(probe.reshape(-1, 3)).reshape(-1, 20)
+                    keep = torch.zeros_like(sec_mask)
+                    keep[sec_mask] = ~((probe_sdf < 0).sum(dim=-1) > 0)
+                    sec_mask = keep
+            # ---- radiance leaving the secondary point towards the primary one
+            hit_points = sec_points[sec_mask]
+            hit_ray_o, hit_ray_d = points[sec_mask], sample_dirs[sec_mask]
+            lightdir = hit_points - (ray_o[sec_mask] if light_pos is None else light_pos)
+            hit_distance = lightdir.norm(dim=-1, keepdim=True)
+            lightdir = lightdir / (lightdir.norm(dim=-1, keepdim=True) + 1e-10)
+            hit_sdf, hit_feature, hit_normal = sdf_network.get_all(hit_points, is_training=sec_is_training)
+            hit_dino = dino_network(hit_points, is_training=sec_is_training)
+            if diff_geo and sec_is_training:
+                hit_points = reparam_points(hit_points, hit_normal.detach(), -hit_ray_d.detach(), hit_sdf)
+            with torch.set_grad_enabled(sec_is_training):
+                sec_results = render_fn(sec_mask, color_network_dict, hit_ray_o, hit_ray_d, hit_points, hit_normal,
+                                        hit_feature, dino_f=hit_dino, light=None, lightdir=lightdir,
+                                        distance=hit_distance, roughness_warmup=roughness_warmup,
+                                        is_training=sec_is_training, EDirectRadiance=True)
+            trace_radiance = sec_results["color"][sec_mask]
+            # ---- primary point lit from the mirror direction by that radiance
+            p_ray_o, p_ray_d, p_points, p_dirs = ray_o[sec_mask], ray_d[sec_mask], points[sec_mask], sample_dirs[sec_mask]
+            p_sdf, p_feature, p_normal = sdf_network.get_all(p_points, is_training=is_training)
+            p_dino = dino_network(p_points, is_training=False)
+            if diff_geo and is_training:
+                p_points = reparam_points(p_points, p_normal.detach(), -p_ray_d.detach(), p_sdf)
+            with torch.set_grad_enabled(is_training):
+                prim = render_fn(sec_mask, color_network_dict, p_ray_o, p_ray_d, p_points, p_normal, p_feature,
+                                 p_dino, light=trace_radiance, lightdir=-p_dirs, distance=None,
+                                 roughness_warmup=roughness_warmup, is_training=is_training, EDirectRadiance=False)
+                blend = torch.ones(sec_mask.shape[0], dtype=torch.float32, device=device)
+                if sec_mask.any():
+                    roughness = prim["specular_roughness"][sec_mask].reshape(-1, 1).detach()
+                    n1 = p_normal.detach()
+                    n1 = n1 / (n1.norm(dim=-1, keepdim=True) + 1e-10)
+                    dot_n_wo = torch.sum(p_dirs * n1, dim=-1, keepdim=True)
+                    distance = torch.norm(p_points - hit_points, dim=-1, keepdim=True)
+                    b = color_network_dict["blend_network"](distance, roughness, dot_n_wo).squeeze(-1)
+                    blend = blend.index_put((sec_mask.nonzero(as_tuple=True)[0],), b)
+            colors.append(prim["color"])
+            coefs.append(blend)
+        idx = points_mask.nonzero(as_tuple=True)[0]
+        indirect_color = indirect_color.index_put((idx,), torch.cat(colors, dim=0))
+        indirect_blend_coef = indirect_blend_coef.index_put((idx,), torch.cat(coefs, dim=0))
+    results.update({"indirect_color": indirect_color.reshape(dots_sh + [3]),
+                    "indirect_blend_coef": indirect_blend_coef.reshape(dots_sh + [1])})
+
+
 def render_camera(camera, sdf_network, raytracer, color_network_dict, dino_network, render_fn, fill_holes=True,
                   handle_edges=True, inv_s=0.0, render_visibility=False, max_num_pts=512, light_pos=None,
                   roughness_warmup=False, indirect_warmup=False, is_training=False):
-    """raytracer.py:1198-1275.  Indirect lighting (render_indirect_lighting) and edge pixels are next-row
-    components: pass indirect_warmup=True, handle_edges=False."""
+    """raytracer.py:1198-1275: trace (+ edge walk), visibility, direct shading, one-bounce indirect term
+    (unless indirect_warmup), edge pixels."""
     results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_holes=fill_holes,
                               detect_edges=handle_edges)
     if render_visibility:
@@ -421,8 +622,11 @@ def render_camera(camera, sdf_network, raytracer, color_network_dict, dino_netwo
                             is_training=is_training, max_num_pts=320000, light_pos=light_pos,
                             roughness_warmup=roughness_warmup)
     if not indirect_warmup:
-        raise NotImplementedError("one-bounce indirect lighting (render_indirect_lighting) is outside the "
-                                  "accelerated hot path in this release; call with indirect_warmup=True")
+        render_indirect_lighting(results, sdf_network, color_network_dict, dino_network, raytracer, render_fn,
+                                 roughness_warmup=roughness_warmup, is_training=is_training, diff_geo=True)
+    if handle_edges and results["edge_mask"].sum() > 0:
+        render_edge_pixels(results, camera, sdf_network, raytracer, color_network_dict, dino_network, render_fn,
+                           is_training=is_training, light_pos=light_pos, roughness_warmup=roughness_warmup)
     return results
 
 

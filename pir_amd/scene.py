@@ -4,7 +4,7 @@ import math
 
 import torch
 
-from .network import SDFNetwork, RenderingNetwork, PointLightNetwork, DINONetwork
+from .network import SDFNetwork, RenderingNetwork, PointLightNetwork, DINONetwork, BlendNetwork
 from .renderer.raytracer import Camera
 
 MODEL_CONFIG = {
@@ -20,7 +20,8 @@ MODEL_CONFIG = {
                                        output_scale=0.1),
     "dino_network": dict(d_in=3, d_out=384, d_hidden=256, n_layers=4, skip_in=[], multires=6, output_bias=0.0,
                          output_scale=1.0),
-    "lr": {"sdf_network": 1e-5, "diffuse_albedo_network": 1e-4, "specular_albedo_network": 1e-4,
+    "blend_network": dict(d_in=3, d_out=1, d_hidden=128, n_layers=4, multires_view=6, squeeze_out=False),
+    "lr": {"sdf_network": 1e-5, "blend_network": 1e-4, "diffuse_albedo_network": 1e-4, "specular_albedo_network": 1e-4,
            "specular_roughness_network": 1e-4},
 }
 LIGHT_OFFSET = (0.2, 0.1, 0.0)     # mitsuba/render_rgb_flash_mat.py:17
@@ -38,6 +39,7 @@ def build_networks(seed=0, device="cpu"):
     mats["point_light_network"].set_light(LIGHT_INTENSITY)
     mats["point_light_network"].light_offset.weight.data = torch.tensor([list(LIGHT_OFFSET)])
     dino = DINONetwork(**MODEL_CONFIG["dino_network"])
+    mats["blend_network"] = BlendNetwork(**MODEL_CONFIG["blend_network"])   # drawn last: earlier weights unchanged
     sdf = sdf.to(device)
     mats = {k: v.to(device) for k, v in mats.items()}
     return sdf, mats, dino.to(device)

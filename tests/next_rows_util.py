@@ -1,0 +1,106 @@
+"""Shared body of the next-rows parity case (edge sampling + one-bounce indirect lighting, tests/golden/next_rows.npz):
+the package's drop-in functions are driven exactly as tools/gen_golden.py drove the reference's."""
+import numpy as np
+import torch
+
+from conftest import load_golden, state_from_npz, rel_err
+
+
+def build(device):
+    from pir_amd import scene
+    from pir_amd.network import SDFNetwork, RenderingNetwork, PointLightNetwork, DINONetwork, BlendNetwork
+    d, rf = load_golden("next_rows.npz"), load_golden("render_fn.npz")
+    net = SDFNetwork(**scene.MODEL_CONFIG["sdf_network"])
+    net.load_state_dict(state_from_npz(d, "sdf."))
+    mats = {}
+    for k in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
+        mats[k] = RenderingNetwork(**dict(scene.MODEL_CONFIG[k], d_hidden=32))
+        mats[k].load_state_dict(state_from_npz(rf, f"mat.{k}."))
+    mats["blend_network"] = BlendNetwork(d_in=3, d_out=1, d_hidden=32, n_layers=4, multires_view=6, squeeze_out=False)
+    mats["blend_network"].load_state_dict(state_from_npz(d, "mat.blend_network."))
+    pl = mats["point_light_network"] = PointLightNetwork(enable_offset=True)
+    pl.set_light(135.0)
+    pl.light_offset.weight.data = torch.tensor([[0.2, 0.1, 0.0]])
+    dino = DINONetwork(**dict(scene.MODEL_CONFIG["dino_network"], d_hidden=32))
+    dino.load_state_dict(state_from_npz(rf, "mat.dino_network."))
+    return d, net.to(device), {k: v.to(device) for k, v in mats.items()}, dino.to(device)
+
+
+def run(device, tol, grad_tol, point_tol, exact_edges=True):
+    """Returns nothing; asserts every stage against the fixture.  `tol` bounds images (max-normalised), `grad_tol`
+    parameter gradients, `point_tol` 3-D positions."""
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer import raytracer as rt
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    d, net, mats, dino = build(device)
+    dev = torch.device(device)
+    cam = rt.Camera(48, 48, torch.from_numpy(d["K"]).to(dev), torch.from_numpy(d["W2C"]).to(dev))
+    tracer = rt.RayTracer()
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=dev.type == "cuda"))
+    inv_s = torch.from_numpy(d["inv_s"]).to(dev)
+    npy = lambda t: t.detach().cpu().numpy()  # noqa: E731
+
+    res = rt.raytrace_camera(cam, net, tracer, fill_holes=False, detect_edges=False)
+    assert (npy(res["convergent_mask"]) != d["trace.mask"]).sum() <= (0 if exact_edges else 1)
+    sob = (rt._sobel_magnitude(res["depth"]) > 1e-2) & res["convergent_mask"]
+    assert (npy(sob) != d["depth_edge_mask"]).sum() <= (0 if exact_edges else 2)
+    # the edge walk starts from the fixture's own inputs, so that it is checked in isolation
+    edge = rt.locate_edge_points(cam, torch.from_numpy(d["trace.points"]).to(dev), net, max_step=16, step_size=1e-3,
+                                 dot_threshold=5e-2, mask=torch.from_numpy(d["depth_edge_mask"]).to(dev))
+    assert np.array_equal(npy(edge["edge_mask"]), d["edge.edge_mask"])
+    assert np.array_equal(npy(edge["edge_pixel_idx"]), d["edge.edge_pixel_idx"])
+    assert np.abs(npy(edge["edge_points"]) - d["edge.edge_points"]).max() < point_tol
+    assert np.abs(npy(edge["edge_uv"]) - d["edge.edge_uv"]).max() < 2e3 * point_tol
+    # and the same through raytrace_camera(detect_edges=True)
+    res = rt.raytrace_camera(cam, net, tracer, fill_holes=False, detect_edges=True)
+    assert (npy(res["edge_mask"]) != d["edge.edge_mask"]).sum() <= (0 if exact_edges else 2)
+    if not np.array_equal(npy(res["edge_mask"]), d["edge.edge_mask"]):
+        res.update(edge)
+        res["convergent_mask"] = torch.from_numpy(d["trace.mask"]).to(dev) & ~res["edge_mask"]
+    assert np.array_equal(npy(res["convergent_mask"]), d["final.mask"])
+
+    pl = mats["point_light_network"]
+    light_pos = cam.get_light_pos(pl.offset)
+    rt.render_light_visibility(res, cam, light_pos, net, inv_s, n_samples=128, max_num_pts=512, is_training=True)
+    rt.render_normal_and_color(res, net, mats, dino, render_fn, is_training=True, max_num_pts=320000,
+                               light_pos=light_pos)
+    mask = d["final.mask"]
+
+    def close(got, ref, name, hard=None):
+        err = np.abs(npy(got) - ref) / np.abs(ref).max()
+        sel = err[mask] if err.shape[:2] == mask.shape and mask.any() else err
+        assert err.max() < (hard or 20 * tol) and np.quantile(sel, 0.97) < tol, (name, err.max(), np.quantile(sel, 0.97))
+
+    close(res["color"], d["direct.color"], "direct.color")
+    rt.render_indirect_lighting(res, net, mats, dino, tracer, render_fn, roughness_warmup=False, is_training=True,
+                                diff_geo=True)
+    lit, lit_ref = npy(res["indirect_color"]).sum(-1) != 0, d["indirect_color"].sum(-1) != 0
+    assert (lit != lit_ref).sum() <= (0 if exact_edges else 2)
+    same = (lit == lit_ref)[..., None]
+    close(res["indirect_color"] * torch.from_numpy(same).to(dev), d["indirect_color"] * same, "indirect_color")
+    close(res["indirect_blend_coef"] * torch.from_numpy(same).to(dev), d["indirect_blend_coef"] * same, "blend_coef")
+    rt.render_edge_pixels(res, cam, net, tracer, mats, dino, render_fn, is_training=True, light_pos=light_pos)
+    close(res["color"], d["final.color"], "final.color")
+    close(res["normal"], d["final.normal"], "final.normal")
+    close(res["vis"], d["final.vis"], "final.vis")
+    assert np.abs(npy(res["points"]) - d["final.points"]).max() < 5 * point_tol + 3e-4 * (not exact_edges)
+    assert npy(res["edge_pos_neg_normal"]).shape == d["edge_pos_neg_normal"].shape
+    close(res["edge_pos_neg_normal"], d["edge_pos_neg_normal"], "edge_pos_neg_normal")
+
+    loss = (res["color"] * res["vis"][..., None] + res["indirect_color"] * res["indirect_blend_coef"]).sum()
+    if exact_edges or np.array_equal(lit, lit_ref):
+        assert abs(loss.item() - float(d["loss"])) < 2 * tol * abs(float(d["loss"]))
+    loss.backward()
+    if not (exact_edges or np.array_equal(lit, lit_ref)):
+        return
+    assert abs(pl.light.grad.item() - float(d["g_light"])) < 2 * tol * abs(float(d["g_light"]))
+    assert rel_err(npy(pl.light_offset.weight.grad), d["g_offset"]) < grad_tol
+    for k, p in net.named_parameters():
+        ref = d[f"g.sdf.{k}"]
+        g = npy(p.grad)
+        assert rel_err(g if g.shape == ref.shape else g[::8], ref) < grad_tol, k
+    for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "blend_network"):
+        for k, p in mats[nm].named_parameters():
+            ref = d[f"g.{nm}.{k}"]
+            g = npy(p.grad) if p.grad is not None else np.zeros(p.shape, np.float32)
+            assert rel_err(g if g.shape == ref.shape else g[::8], ref) < grad_tol, (nm, k)

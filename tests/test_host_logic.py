@@ -70,8 +70,6 @@ def test_cpu_tracer_and_render_fn_match_reference():
     res = raytrace_camera(cam, net, RayTracer())
     assert np.array_equal(res["convergent_mask"].numpy(), t["cam_mask"])
     assert np.abs(res["depth"].numpy() - t["cam_depth"]).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        raytrace_camera(cam, net, RayTracer(), detect_edges=True)
     # render_fn with small material networks
     d = load_golden("render_fn.npz")
     small = dict(scene.MODEL_CONFIG)
@@ -97,6 +95,13 @@ def test_cpu_tracer_and_render_fn_match_reference():
     out = reparam_points(torch.from_numpy(rp["points"]), torch.from_numpy(rp["grads"]), torch.from_numpy(rp["dirs"]), s)
     (out * torch.from_numpy(rp["cw"])).sum().backward()
     assert np.array_equal(out.detach().numpy(), rp["out"]) and rel_err(s.grad, rp["g_sdf"]) < 1e-6
+
+
+def test_edges_and_indirect_lighting_match_reference_on_cpu():
+    """Drop-in locate_edge_points / render_indirect_lighting / render_edge_pixels (torch CPU path of the package)
+    against the reference's outputs, forward and backward."""
+    import next_rows_util
+    next_rows_util.run("cpu", tol=1e-4, grad_tol=3e-4, point_tol=1e-6)
 
 
 def test_ggx_cpu_formula_matches_reference():

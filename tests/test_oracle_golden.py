@@ -226,3 +226,72 @@ def test_end_to_end_tile(tag):
             if g.shape != ref.shape:
                 g = g[::8]
             assert rel_err(g, ref) < 3e-4, (nm, k)
+
+
+BLEND_CFG = dict(multires_view=6, squeeze_out=False)
+
+
+def test_next_rows_edges_and_indirect():
+    """locate_edge_points, render_indirect_lighting and render_edge_pixels of the reference on a 48x48 view of a
+    strongly perturbed sphere (24 edge pixels, 70 pixels with a secondary hit), forward and backward."""
+    d = load_golden("next_rows.npz")
+    rf = load_golden("render_fn.npz")
+    sdf_params = {k: v.clone().requires_grad_(True) for k, v in state_from_npz(d, "sdf.").items()}
+    layers = O.mlp_layers(sdf_params)
+    mats, dino, mat_params = mats_from(rf, requires_grad=True)
+    bst = {k: v.clone().requires_grad_(True) for k, v in state_from_npz(d, "mat.blend_network.").items()}
+    mats["blend_network"] = dict(layers=O.mlp_layers(bst), cfg=BLEND_CFG)
+    mat_params["blend_network"] = bst
+    cam = O.CameraRays(48, 48, torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"]))
+    tabs, tracer = _tables(), O.Tracer()
+    light = torch.tensor(135.0, requires_grad=True)
+    off = torch.tensor([[0.2, 0.1, 0.0]], requires_grad=True)
+    inv_s = torch.from_numpy(d["inv_s"])
+
+    res = O.raytrace_camera(cam, layers, tracer)
+    assert np.array_equal(res["convergent_mask"].numpy(), d["trace.mask"])
+    # the Sobel restatement (kornia's published algorithm, unpinned) reproduces the mask stored with the fixture
+    edge_in = (O.sobel_magnitude(res["depth"]) > 1e-2) & res["convergent_mask"]
+    assert np.array_equal(edge_in.numpy(), d["depth_edge_mask"])
+    edge = O.locate_edge_points(cam, res["points"], layers, edge_in)
+    assert np.array_equal(edge["edge_mask"].numpy(), d["edge.edge_mask"])
+    assert np.array_equal(edge["edge_pixel_idx"].numpy(), d["edge.edge_pixel_idx"])
+    assert np.abs(edge["edge_points"].numpy() - d["edge.edge_points"]).max() < 1e-6
+    assert np.abs(edge["edge_uv"].numpy() - d["edge.edge_uv"]).max() < 1e-3
+    res.update(edge)
+    res["convergent_mask"] = res["convergent_mask"] & ~res["edge_mask"]
+
+    # visibility over hits + edge pixels, then direct shading
+    light_pos = cam.light_pos(off)
+    m_all = (res["convergent_mask"] | res["edge_mask"]).reshape(-1)
+    vis = torch.zeros(48 * 48).index_put(
+        (m_all.nonzero()[:, 0],),
+        O.light_visibility(light_pos, res["points"].reshape(-1, 3)[m_all], layers, inv_s, 128, True))
+    res["vis"] = vis.reshape(48, 48)
+    out = O.shade_traced(res, layers, mats, dino, tabs, light, light_pos=light_pos, is_training=True)
+    for k in ("color", "normal"):
+        res[k] = out[k].reshape(48, 48, 3)
+    assert rel_err(res["color"].detach(), d["direct.color"]) < TOL
+    ic, ib = O.render_indirect(res, layers, mats, dino, tabs, tracer, light, is_training=True)
+    assert np.array_equal((ic.detach().numpy().sum(-1) != 0), (d["indirect_color"].sum(-1) != 0))
+    assert rel_err(ic.detach(), d["indirect_color"]) < TOL
+    assert rel_err(ib.detach(), d["indirect_blend_coef"]) < TOL
+    O.render_edge_pixels(res, cam, layers, mats, dino, tabs, tracer, light, light_pos=light_pos, is_training=True)
+    assert rel_err(res["color"].detach(), d["final.color"]) < TOL
+    assert rel_err(res["normal"].detach(), d["final.normal"]) < TOL
+    assert np.abs(res["points"].numpy() - d["final.points"]).max() < 1e-6
+    assert rel_err(res["edge_pos_neg_normal"].detach(), d["edge_pos_neg_normal"]) < TOL
+
+    loss = (res["color"] * res["vis"][..., None] + ic * ib).sum()
+    assert abs(loss.item() - float(d["loss"])) < 1e-4 * abs(float(d["loss"]))
+    loss.backward()
+    assert rel_err(light.grad, d["g_light"]) < 1e-4
+    assert rel_err(off.grad, d["g_offset"]) < 2e-4
+    for k, p in sdf_params.items():
+        g, ref = p.grad.numpy(), d[f"g.sdf.{k}"]
+        assert rel_err(g[::8] if g.shape != ref.shape else g, ref) < 3e-4, k
+    for nm, ps in mat_params.items():
+        for k, p in ps.items():
+            g = p.grad.numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
+            ref = d[f"g.{nm}.{k}"]
+            assert rel_err(g[::8] if g.shape != ref.shape else g, ref) < 3e-4, (nm, k)

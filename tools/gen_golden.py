@@ -86,13 +86,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="", help="comma-separated fixture file names to (re)write; default: all")
     args = ap.parse_args()
     out_dir = os.path.abspath(args.out)
     os.makedirs(out_dir, exist_ok=True)
 
+    only = set(x for x in args.only.split(",") if x)
+
+    def save(path, **d):
+        if only and os.path.basename(path) not in only:
+            return
+        np.savez_compressed(path, **d)
+
     _install_stubs()
     sys.path.insert(0, args.ref)
-    from src.network import SDFNetwork, RenderingNetwork, PointLightNetwork, DINONetwork  # noqa
+    from src.network import SDFNetwork, RenderingNetwork, PointLightNetwork, DINONetwork, BlendNetwork  # noqa
     from src.renderer.renderer_ggx import GGXColocatedRenderer  # noqa
     import src.renderer.raytracer as rt  # noqa
 
@@ -133,7 +141,7 @@ def main():
         loss2.backward()
         d["grad_x_nofeat"] = _np(xt2.grad)
         d.update({"g2." + k: v for k, v in grads_subsample(net.named_parameters()).items()})
-        np.savez_compressed(os.path.join(out_dir, name), **d)
+        save(os.path.join(out_dir, name), **d)
         return net
 
     sdf_fixture(SDF_SMALL, "sdf_small.npz", 0)
@@ -144,7 +152,7 @@ def main():
     torch.manual_seed(0)
     net_bumpy = SDFNetwork(**SDF_FULL)
     perturb(net_bumpy, 1, 0.02)
-    np.savez_compressed(os.path.join(out_dir, "sdf_full_bumpy_weights.npz"), **state_to_np("w.", net_bumpy))
+    save(os.path.join(out_dir, "sdf_full_bumpy_weights.npz"), **state_to_np("w.", net_bumpy))
 
     # --------------------------------------------------------------- camera
     cam = standard_camera(rt.Camera, 40, 24, roty=0.3, shift=(3.0, -2.0))
@@ -152,7 +160,7 @@ def main():
     ro, rd, rdn = cam.get_rays(uv)
     m, dmin, dmax = rt.intersect_sphere(ro.view(-1, 3), rd.view(-1, 3), r=1.0)
     off = torch.tensor([[0.2, 0.1, 0.0]])
-    np.savez_compressed(os.path.join(out_dir, "camera.npz"), K=_np(cam.K), W2C=_np(cam.W2C), W=40, H=24,
+    save(os.path.join(out_dir, "camera.npz"), K=_np(cam.K), W2C=_np(cam.W2C), W=40, H=24,
                         uv=_np(uv), ray_o=_np(ro), ray_d=_np(rd), ray_d_norm=_np(rdn), mask=_np(m),
                         min_dis=_np(dmin), max_dis=_np(dmax), offset=_np(off),
                         light_pos=_np(cam.get_light_pos(off)))
@@ -176,7 +184,7 @@ def main():
                  convergent_mask=_np(full["convergent_mask"]), points=_np(full["points"]), sdf=_np(full["sdf"]),
                  distance=_np(full["distance"]), cam_depth=_np(res["depth"]), cam_mask=_np(res["convergent_mask"]),
                  cam_points=_np(res["points"]))
-        np.savez_compressed(os.path.join(out_dir, name), **d)
+        save(os.path.join(out_dir, name), **d)
         return cam, res
 
     trace_fixture(net_full, "trace_std64.npz", 64, 64)
@@ -211,7 +219,7 @@ def main():
     vis_d["light_pos_side"] = _np(lp2)
     vis_d["vis_side128"] = _np(rt.light_visibility(lp2, pts, net_bumpy, inv_s, n_samples=128, is_training=False))
     vis_d["K"], vis_d["W2C"] = _np(cam.K), _np(cam.W2C)
-    np.savez_compressed(os.path.join(out_dir, "visibility.npz"), **vis_d)
+    save(os.path.join(out_dir, "visibility.npz"), **vis_d)
 
     # ------------------------------------------------------------------ GGX
     ggx = GGXColocatedRenderer()
@@ -255,7 +263,7 @@ def main():
     o = ggx(lrgb, dist, nrm, ldir, vdir, kd, ks, alpha, EDirectRadiance=False)
     ggx_d["rgblight.light"] = _np(lrgb)
     ggx_d["rgblight.rgb"] = _np(o["rgb"])
-    np.savez_compressed(os.path.join(out_dir, "ggx.npz"), **ggx_d)
+    save(os.path.join(out_dir, "ggx.npz"), **ggx_d)
 
     # --------------------------------------------------------------- reparam
     g = torch.Generator().manual_seed(5)
@@ -267,7 +275,7 @@ def main():
     rp = rt.reparam_points(p0, gr, dr, sv)
     cw = torch.randn(128, 3, generator=g)
     (rp * cw).sum().backward()
-    np.savez_compressed(os.path.join(out_dir, "reparam.npz"), points=_np(p0), grads=_np(gr), dirs=_np(dr), sdf=_np(sv),
+    save(os.path.join(out_dir, "reparam.npz"), points=_np(p0), grads=_np(gr), dirs=_np(dr), sdf=_np(sv),
                         out=_np(rp), cw=_np(cw), g_sdf=_np(sv.grad))
 
     # ------------------------------------------------- render_fn / materials
@@ -321,7 +329,7 @@ def main():
         if "lightdir" in kw:
             rf_d["offset.lightdir"], rf_d["offset.distance"] = _np(kw["lightdir"]), _np(kw["distance"])
     rf_d.update(mat_state)
-    np.savez_compressed(os.path.join(out_dir, "render_fn.npz"), **rf_d)
+    save(os.path.join(out_dir, "render_fn.npz"), **rf_d)
 
     # ----------------------------------------------------- end-to-end 32x32
     cam = standard_camera(rt.Camera, 32, 32, roty=0.25)
@@ -359,7 +367,69 @@ def main():
         e2e.update({f"{tag}.g.sdf." + k: v for k, v in grads_subsample(net_bumpy.named_parameters()).items()})
         for nm in MAT:
             e2e.update({f"{tag}.g.{nm}." + k: v for k, v in grads_subsample(cnd[nm].named_parameters()).items()})
-    np.savez_compressed(os.path.join(out_dir, "e2e_tile.npz"), **e2e)
+    save(os.path.join(out_dir, "e2e_tile.npz"), **e2e)
+
+    # --------------------------------------- next rows: edge sampling + one-bounce indirect lighting (48x48)
+    # kornia is not installable here, so the depth-edge mask that raytrace_camera would get from
+    # kornia.filters.sobel is computed right here from kornia's published algorithm (normalised 3x3 Sobel
+    # cross-correlation, replicate padding, sqrt(gx^2+gy^2+1e-6)) and stored as an INPUT of the fixture;
+    # locate_edge_points / render_edge_pixels / render_indirect_lighting are the reference's own code.
+    # Scene: the seed-0 sphere with a strong perturbation (rel 0.1), which has silhouettes inside the image and
+    # concavities that secondary rays hit.
+    BLEND = dict(d_in=3, d_out=1, d_hidden=32, n_layers=4, multires_view=6, squeeze_out=False)
+    torch.manual_seed(41)
+    cnd["blend_network"] = BlendNetwork(**BLEND)
+    torch.manual_seed(0)
+    net_edge = SDFNetwork(**SDF_FULL)
+    perturb(net_edge, 1, 0.1)
+    cam = standard_camera(rt.Camera, 48, 48, roty=-0.6)
+    nx = dict(K=_np(cam.K), W2C=_np(cam.W2C), W=48, H=48, inv_s=_np(inv_s))
+    nx.update(state_to_np("mat.blend_network.", cnd["blend_network"]))
+    nx.update(state_to_np("sdf.", net_edge))
+    for m_ in [net_edge, dino_net] + [v for v in cnd.values()]:
+        m_.zero_grad()
+    cnd["point_light_network"].light_offset.weight.data = torch.tensor([[0.2, 0.1, 0.0]])
+    results = rt.raytrace_camera(cam, net_edge, tracer, fill_holes=False, detect_edges=False)
+    dep = results["depth"]
+    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+    padded = F.pad(dep[None, None], (1, 1, 1, 1), mode="replicate")
+    gxy = F.conv2d(padded, torch.stack([kx, kx.t()])[:, None])[0]
+    depth_grad_norm = torch.sqrt(gxy[0] * gxy[0] + gxy[1] * gxy[1] + 1e-6)
+    depth_edge_mask = (depth_grad_norm > 1e-2) & results["convergent_mask"]
+    nx["depth_edge_mask"] = _np(depth_edge_mask)
+    nx["trace.points"], nx["trace.mask"], nx["trace.depth"] = _np(results["points"]), _np(results["convergent_mask"]), _np(dep)
+    edge = rt.locate_edge_points(cam, results["points"], net_edge, max_step=16, step_size=1e-3, dot_threshold=5e-2,
+                                 max_num_rays=200000, mask=depth_edge_mask)
+    nx.update({"edge." + k: _np(v) for k, v in edge.items()})
+    results.update(edge)
+    results["convergent_mask"] &= ~results["edge_mask"]
+    light_pos = cam.get_light_pos(cnd["point_light_network"].offset)
+    rt.render_light_visibility(results, cam, light_pos, net_edge, inv_s, n_samples=128, max_num_pts=512,
+                               is_training=True)
+    rt.render_normal_and_color(results, net_edge, cnd, dino_net, render_fn, is_training=True, max_num_pts=320000,
+                               light_pos=light_pos)
+    nx["direct.color"] = _np(results["color"])
+    rt.render_indirect_lighting(results, net_edge, cnd, dino_net, tracer, render_fn, roughness_warmup=False,
+                                is_training=True, diff_geo=True)
+    nx["indirect_color"], nx["indirect_blend_coef"] = _np(results["indirect_color"]), _np(results["indirect_blend_coef"])
+    rt.render_edge_pixels(results, cam, net_edge, tracer, cnd, dino_net, render_fn, is_training=True,
+                          light_pos=light_pos)
+    nx["final.color"], nx["final.normal"], nx["final.points"] = _np(results["color"]), _np(results["normal"]), _np(results["points"])
+    nx["final.vis"], nx["final.mask"] = _np(results["vis"]), _np(results["convergent_mask"])
+    nx["final.uv"] = _np(results["uv"])
+    nx["edge_pos_neg_normal"] = _np(results["edge_pos_neg_normal"])
+    pred = results["color"] * results["vis"][..., None] + results["indirect_color"] * results["indirect_blend_coef"]
+    loss = pred.sum()
+    loss.backward()
+    nx["loss"] = np.float64(loss.item())
+    nx["g_offset"] = _np(cnd["point_light_network"].light_offset.weight.grad)
+    nx["g_light"] = _np(cnd["point_light_network"].light.grad)
+    nx.update({"g.sdf." + k: v for k, v in grads_subsample(net_edge.named_parameters()).items()})
+    for nm in list(MAT) + ["blend_network"]:
+        nx.update({f"g.{nm}." + k: v for k, v in grads_subsample(cnd[nm].named_parameters()).items()})
+    print("next rows: hits", int(nx["trace.mask"].sum()), "edge px", int(nx["edge.edge_mask"].sum()),
+          "indirect px", int((nx["indirect_color"].sum(-1) != 0).sum()), "loss", nx["loss"])
+    save(os.path.join(out_dir, "next_rows.npz"), **nx)
 
     # known-answer GGX cases of SURVEY.md Appendix A are asserted directly in the tests.
     tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
