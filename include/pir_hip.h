@@ -79,6 +79,30 @@ int pir_trace_status(const void* workspace, int* host_status, void* stream);
 int pir_camera_rays(long n, int width, const float* uv, const float* cam21, float radius, float* ray_o, float* ray_d,
                     float* ray_d_norm, unsigned char* hit, float* min_dis, float* max_dis, void* stream);
 
+/* ---- light-visibility march (src/renderer/raytracer.py:669-729, light_visibility) -------------------- */
+/* A march has n = n_samples - 10 samples per surface point (the reference drops the last 10 of
+ * linspace(0, 1, n_samples), :682), n <= 512.  rays_d [bs,3] = normalize(points - light_pos), length [bs] =
+ * |points - light_pos| (:676-678).  The SDF value and normal of the samples come from pir_sdf_get_all. */
+
+/* Sample positions x [bs*n, 3] = light_pos + rays_d * mid, mid = z + dists/2, z = linspace * length (:682-692). */
+int pir_visibility_points(const float* light_pos, const float* rays_d, const float* length, long bs, int n_samples,
+                          float* x, void* stream);
+/* Backward of the above: d x [bs*n,3] -> per-point partial d light_pos [bs,3] (sum over bs for the total),
+ * d rays_d [bs,3], d length [bs]. */
+int pir_visibility_points_backward(const float* g_x, const float* rays_d, const float* length, long bs, int n_samples,
+                                   float* g_light_pos_point, float* g_rays_d, float* g_length, void* stream);
+/* NeuS-style opacity compositing (:700-727): from sdf [bs*n] and normal [bs*n,3] of the samples,
+ * alpha = clip((sigma((sdf - h) inv_s) - sigma((sdf + h) inv_s) + 1e-5) / (sigma((sdf - h) inv_s) + 1e-5), 0, 1) with
+ * h = -relu(-rays_d.normal) dists / 2, vis [bs] = 1 - sum_s alpha_s prod_{j<s} (1 - alpha_j + 1e-7).
+ * inv_s: device scalar. */
+int pir_visibility_forward(const float* sdf, const float* normal, const float* rays_d, const float* length,
+                           const float* inv_s, long bs, int n_samples, float* vis, void* stream);
+/* Analytic backward of pir_visibility_forward: d vis [bs] -> d sdf [bs*n], d normal [bs*n,3], d rays_d [bs,3],
+ * d length [bs] (what autograd derives for :700-727; samples whose sigmoids saturate get exact zeros). */
+int pir_visibility_backward(const float* g_vis, const float* sdf, const float* normal, const float* rays_d,
+                            const float* length, const float* inv_s, long bs, int n_samples, float* g_sdf,
+                            float* g_normal, float* g_rays_d, float* g_length, void* stream);
+
 /* ---- GGX point-light shader (src/renderer/renderer_ggx.py:39-127, GGXColocatedRenderer.forward) ------ */
 
 /* light: device scalar, or [P,3] radiance when light_is_rgb; direct_radiance = EDirectRadiance. */

@@ -60,6 +60,14 @@ def _declare(L):
     L.pir_ggx_forward.argtypes = [lg, vp, i32, i32] + [vp] * 8 + [i32, vp, i32, vp, vp, vp, vp]
     L.pir_ggx_backward.restype = i32
     L.pir_ggx_backward.argtypes = [lg, vp, i32, i32] + [vp] * 8 + [i32, vp, i32] + [vp] * 10 + [vp]
+    L.pir_visibility_points.restype = i32
+    L.pir_visibility_points.argtypes = [vp, vp, vp, lg, i32, vp, vp]
+    L.pir_visibility_points_backward.restype = i32
+    L.pir_visibility_points_backward.argtypes = [vp, vp, vp, lg, i32, vp, vp, vp, vp]
+    L.pir_visibility_forward.restype = i32
+    L.pir_visibility_forward.argtypes = [vp, vp, vp, vp, vp, lg, i32, vp, vp]
+    L.pir_visibility_backward.restype = i32
+    L.pir_visibility_backward.argtypes = [vp, vp, vp, vp, vp, vp, lg, i32, vp, vp, vp, vp, vp]
     L.pir_profile_enable.restype = i32
     L.pir_profile_enable.argtypes = [i32]
     L.pir_profile_read.restype = i32

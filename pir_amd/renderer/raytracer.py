@@ -400,8 +400,9 @@ def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_ho
     return results
 
 
-def light_visibility(light_pos, points, sdf_network, inv_s, n_samples=128, is_training=True):
-    """Transmittance from the light to each surface point by a NeuS-style march (raytracer.py:669-729)."""
+def _light_visibility_torch(light_pos, points, sdf_network, inv_s, n_samples, is_training):
+    """The march written with PyTorch ops: CPU host-logic tests, networks the kernels do not cover, and an inv_s
+    that needs a gradient (the reference always passes a detached one, render_surface.py:241)."""
     device = points.device
     bs = points.shape[0]
     delta = points - light_pos
@@ -429,6 +430,27 @@ def light_visibility(light_pos, points, sdf_network, inv_s, n_samples=128, is_tr
     trans = torch.cumprod(torch.cat([torch.ones(bs, 1, device=device), 1.0 - alpha + 1e-7], -1), -1)[:, :-1]
     acc_map = (1.0 - (alpha * trans).sum(dim=-1, keepdim=True)).reshape(bs)
     return acc_map if is_training else acc_map.clone().detach()
+
+
+def light_visibility(light_pos, points, sdf_network, inv_s, n_samples=128, is_training=True):
+    """Transmittance from the light to each surface point by a NeuS-style march (raytracer.py:669-729).
+
+    On the GPU: sample positions (pir_visibility_points), value + normal of the n_samples-10 samples per point
+    (pir_sdf_get_all), opacity compositing (pir_visibility_forward); their backward kernels under autograd."""
+    inv_s = torch.as_tensor(inv_s, dtype=torch.float32, device=points.device)
+    native = (points.is_cuda and getattr(sdf_network, "hip_supported", lambda: False)() and not inv_s.requires_grad
+              and 2 <= n_samples - 10 <= 512)
+    if not native:
+        return _light_visibility_torch(light_pos, points, sdf_network, inv_s, n_samples, is_training)
+    from .. import visibility_hip
+    with torch.set_grad_enabled(is_training and torch.is_grad_enabled()):
+        delta = points - light_pos
+        length = torch.norm(delta, dim=-1, keepdim=True)
+        rays_d = delta / length
+        pts = visibility_hip.march_points(light_pos, rays_d, length, n_samples)
+        sdf, grad = sdf_network.get_sdf_normal(pts, is_training=is_training)
+        vis = visibility_hip.composite(sdf, grad, rays_d, length, inv_s, n_samples)
+    return vis if is_training else vis.detach()
 
 
 def render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_samples=128, max_num_pts=2500,

@@ -166,3 +166,56 @@ def test_light_visibility_matches_reference(n_samples):
     v2 = light_visibility(torch.from_numpy(d["light_pos_side"]).cuda(), pts, net, inv_s, 128, is_training=False)
     if n_samples == 128:
         assert rel_err(v2.cpu().numpy(), d["vis_side128"]) < 1e-4 and not v2.requires_grad
+
+
+def test_visibility_kernels_match_torch_formula_and_edge_cases():
+    """pir_visibility_* against the same march written with PyTorch ops on 5000 points (both use the HIP SDF
+    kernels), forward and every gradient; saturated samples must get exactly-zero gradients (the SDF backward
+    skips them); empty input, the 512-sample maximum and its rejection beyond."""
+    import ctypes
+    from pir_amd import _lib, visibility_hip
+    from pir_amd.renderer import raytracer as rt
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    g = torch.Generator().manual_seed(11)
+    pts = (torch.nn.functional.normalize(torch.randn(5000, 3, generator=g), dim=-1) *
+           (0.45 + 0.1 * torch.rand(5000, 1, generator=g))).cuda()
+    inv_s = torch.tensor([[20.0855]], device="cuda")
+    w = torch.rand(5000, generator=g).cuda()
+    outs = []
+    for fn in (rt.light_visibility, rt._light_visibility_torch):
+        net.zero_grad()
+        lp = torch.tensor([[0.3, 0.2, -2.9]], device="cuda", requires_grad=True)
+        vis = fn(lp, pts, net, inv_s, 128, True)
+        (vis * w).sum().backward()
+        outs.append((vis.detach(), lp.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (v0, l0, g0), (v1, l1, g1) = outs
+    assert (v0 - v1).abs().max().item() < 2e-5
+    assert 0.02 < (v0 < 0.5).float().mean().item() < 0.98          # the case has lit and shadowed points
+    assert rel_err(l0.cpu().numpy(), l1.cpu().numpy()) < 2e-4
+    for k in g0:
+        assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-4, k
+
+    # exact zeros where both sigmoids saturate
+    bs, n = 64, 118
+    sdf = torch.full((bs * n,), 2.0, device="cuda")
+    nrm = torch.randn(bs * n, 3, device="cuda")
+    d = torch.nn.functional.normalize(torch.randn(bs, 3, device="cuda"), dim=-1)
+    L = torch.full((bs, 1), 2.5, device="cuda")
+    s_, n_ = sdf.clone().requires_grad_(True), nrm.clone().requires_grad_(True)
+    vis = visibility_hip.composite(s_, n_, d, L, inv_s, 128)
+    vis.sum().backward()
+    assert torch.count_nonzero(s_.grad).item() == 0 and torch.count_nonzero(n_.grad).item() == 0
+    assert (vis - 1.0).abs().max().item() < 2e-3
+
+    # empty input, maximum march length (n = 512), rejection beyond it
+    assert rt.light_visibility(torch.zeros(1, 3, device="cuda"), torch.zeros(0, 3, device="cuda"), net, inv_s,
+                               128, False).shape == (0,)
+    p8 = pts[:8]
+    lp = torch.tensor([[0.3, 0.2, -2.9]], device="cuda")
+    big = rt.light_visibility(lp, p8, net, inv_s, 522, False)
+    ref = rt._light_visibility_torch(lp, p8, net, inv_s, 522, False)
+    assert (big - ref).abs().max().item() < 5e-5
+    Lib = _lib.lib()
+    rc = Lib.pir_visibility_forward(_lib.ptr(sdf), _lib.ptr(nrm), _lib.ptr(d), _lib.ptr(L.reshape(-1).contiguous()),
+                                    _lib.ptr(inv_s.reshape(1)), 1, 523, _lib.ptr(vis.detach()), _lib.stream_ptr())
+    assert rc == 1
