@@ -125,7 +125,9 @@ int pir_ggx_backward(long P, const float* light, int light_is_rgb, int direct_ra
 
 /* Kernel families timed by the optional HIP-event profiler. */
 enum { PIR_K_SDF_EVAL = 0, PIR_K_SDF_GETALL = 1, PIR_K_TRACE_STEP = 2, PIR_K_SAMPLER = 3, PIR_K_BISECT = 4,
-       PIR_K_BWD_SWEEP = 5, PIR_K_WGRAD = 6, PIR_K_GGX_FWD = 7, PIR_K_GGX_BWD = 8, PIR_K_COUNT = 9 };
+       PIR_K_BWD_SWEEP = 5, PIR_K_WGRAD = 6, PIR_K_GGX_FWD = 7, PIR_K_GGX_BWD = 8,
+       PIR_K_SDF_EVAL_FEAT = 9, PIR_K_SDF_GETALL_FEAT = 10,   /* the variants that also write the 256 features */
+       PIR_K_COUNT = 11 };
 /* When enabled every kernel launch of the families above is bracketed by hipEvents on its stream. */
 int pir_profile_enable(int on);
 /* Synchronises and returns, per family id < n_ids, the number of launches, their summed duration (ms) and the

@@ -182,7 +182,7 @@ int pir_sdf_forward(const void* packed, const float* x, long M, float* sdf, floa
   SdfPacked pk = make_packed(packed);
   const long ntiles = (M + kWgPts - 1) / kWgPts;
   dim3 grid((unsigned)(ntiles < (1L << 30) ? ntiles : (1L << 30)));
-  PirProfScope prof(PIR_K_SDF_EVAL, (double)M, stream);
+  PirProfScope prof(feat ? PIR_K_SDF_EVAL_FEAT : PIR_K_SDF_EVAL, (double)M, stream);
   if (feat)
     hipLaunchKernelGGL(sdf_eval_kernel<kWantFeat>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf, feat,
                        (float*)nullptr, (f32x4*)nullptr);
@@ -204,7 +204,7 @@ int pir_sdf_get_all(const void* packed, const float* x, long M, float* sdf, floa
   if (nwg > ntiles) nwg = ntiles;
   SdfPacked pk = make_packed(packed);
   dim3 grid((unsigned)nwg);
-  PirProfScope prof(PIR_K_SDF_GETALL, (double)M, stream);
+  PirProfScope prof(feat ? PIR_K_SDF_GETALL_FEAT : PIR_K_SDF_GETALL, (double)M, stream);
   if (feat)
     hipLaunchKernelGGL(sdf_eval_kernel<kWantFeat | kWantNormal>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x,
                        M, sdf, feat, normal, (f32x4*)scratch);
