@@ -186,8 +186,9 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       gemm_phase<kTPW, true>(pk.mats, kR8, kTPW * w, lds, 0, acc);
       __syncthreads();
     }
-    f32x16 accpe[kSets][1];
-    zero_acc(accpe);
+    // gradient w.r.t. the encoding slots = lin4's share (skip connection) + lin0's share.  The first is parked in
+    // global memory between the two products instead of occupying 32 registers through layers 3..0.
+    float* pe_park = sc.pe_tmp + ((size_t)blockIdx.x * 2 + (w & 1)) * (32 * 64) + lane;
 #pragma nounroll
     for (int l = 8; l >= 1; --l) {
       // acc = (u_l, y_l): gradients w.r.t. the input of layer l  ->  (q_{l-1}, zb_{l-1})
@@ -219,11 +220,26 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       if (m >= 1) {
         zero_acc(acc);
         gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[m], kTPW * w, lds, 0, acc, pre, m >= 2, kRev[m >= 2 ? m - 1 : m]);
-        if (m == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
-      } else {
-        if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
+        if (m == 4 && w < 2) {
+          f32x16 accpe[kSets][1];
+          zero_acc(accpe);
+          gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+#pragma unroll
+          for (int s2 = 0; s2 < kSets; ++s2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pe_park[(16 * s2 + r) * 64] = accpe[s2][0][r];
+        }
       }
       __syncthreads();
+    }
+    f32x16 accpe[kSets][1];
+    zero_acc(accpe);
+    if (w < 2) {
+      gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
+#pragma unroll
+      for (int s2 = 0; s2 < kSets; ++s2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accpe[s2][0][r] += pe_park[(16 * s2 + r) * 64];
     }
 
     // ------------------------------------------------------------------ d L / d x through the encoding
