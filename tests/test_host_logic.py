@@ -147,3 +147,35 @@ def test_data_parallel_grad_bucket_gloo_world2(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok") == 2
+
+
+def test_image_losses_match_reference():
+    from pir_amd.models.image_losses import PyramidL2Loss, ssim_loss_fn
+    d = load_golden("image_losses.npz")
+    gt, mask = torch.from_numpy(d["gt"]), torch.from_numpy(d["mask"])
+    pyr = PyramidL2Loss(use_cuda=False)
+    for tag, fn in (("pyramid", lambda p: pyr(p, gt)), ("ssim", lambda p: ssim_loss_fn(p, gt)),
+                    ("ssim_masked", lambda p: ssim_loss_fn(p, gt, mask))):
+        pred = torch.from_numpy(d["pred"]).requires_grad_(True)
+        v = fn(pred)
+        v.backward()
+        assert abs(v.item() - float(d[tag])) < 1e-6 * max(1.0, abs(float(d[tag]))), tag
+        assert rel_err(pred.grad, d[tag + ".grad"]) < 1e-5, tag
+
+
+def test_training_step_matches_reference_on_cpu(tmp_path):
+    """One stage-2 iteration (render_surface.py:545-699 executed from the reference's text by tools/gen_golden.py):
+    view/crop choice, every loss term, every gradient, the optimizer schedule; then the checkpoint round trip."""
+    import glob
+    import train_step_util
+    from pir_amd import loader
+    out = train_step_util.run("cpu", tol=1e-4, grad_tol=3e-4)
+    assert out["render_shadow"]
+    d, state = train_step_util.build_state("cpu")
+    path = loader.save_pir_ckpt(str(tmp_path), 5000, state.sdf_network, state.color_network_dict)
+    with torch.no_grad():
+        state.sdf_network.lin0.bias.add_(1.0)
+    assert loader.load_pir_ckpt(glob.glob(str(tmp_path / "ckpt_*.pth")), state.sdf_network,
+                                state.color_network_dict) == 5000 and loader.path2step(path) == 5000
+    assert np.array_equal(state.sdf_network.lin0.bias.detach().numpy(), d["sdf.lin0.bias"])
+    assert loader.load_dino_ckpt([], state.dino_network) == -1

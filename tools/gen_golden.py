@@ -431,6 +431,122 @@ def main():
           "indirect px", int((nx["indirect_color"].sum(-1) != 0).sum()), "loss", nx["loss"])
     save(os.path.join(out_dir, "next_rows.npz"), **nx)
 
+    # ------------------------------------------- training glue: image losses + one training step
+    # kornia stand-ins (kornia is not installable here; parity with kornia itself stays unpinned): its published
+    # algorithms for the three calls the reference makes -- normalised Sobel magnitude, and flat-kernel
+    # erosion / closing with geodesic borders (= min / max pooling that ignores out-of-image pixels).
+    kornia = sys.modules["kornia"]
+    kornia.filters = types.ModuleType("kornia.filters")
+    kornia.morphology = types.ModuleType("kornia.morphology")
+
+    def _k_sobel(x):
+        kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+        b, c, h, w = x.shape
+        xp = F.pad(x.reshape(b * c, 1, h, w), (1, 1, 1, 1), mode="replicate")
+        gg = F.conv2d(xp, torch.stack([kx, kx.t()])[:, None])
+        return torch.sqrt(gg[:, 0] ** 2 + gg[:, 1] ** 2 + 1e-6).reshape(b, c, h, w)
+
+    def _k_erosion(x, kernel):
+        k = kernel.shape[-1]
+        return -F.max_pool2d(-x, k, stride=1, padding=k // 2)
+
+    def _k_dilation(x, kernel):
+        k = kernel.shape[-1]
+        return F.max_pool2d(x, k, stride=1, padding=k // 2)
+
+    kornia.filters.sobel = _k_sobel
+    kornia.morphology.erosion = _k_erosion
+    kornia.morphology.closing = lambda x, kernel: _k_erosion(_k_dilation(x, kernel), kernel)
+    import src.models.image_losses as il  # noqa
+
+    g = torch.Generator().manual_seed(51)
+    pred = torch.rand(1, 3, 48, 48, generator=g).requires_grad_(True)
+    gt = (pred.detach() + 0.2 * torch.randn(1, 3, 48, 48, generator=g)).clamp(0, 1)
+    lmask = torch.zeros(1, 1, 48, 48, dtype=torch.bool)
+    lmask[:, :, 6:40, 9:44] = True
+    pyr = il.PyramidL2Loss(use_cuda=False)
+    il_d = dict(pred=_np(pred), gt=_np(gt), mask=_np(lmask))
+    for tag, fn in (("pyramid", lambda: pyr(pred, gt)), ("ssim", lambda: il.ssim_loss_fn(pred, gt)),
+                    ("ssim_masked", lambda: il.ssim_loss_fn(pred, gt, lmask))):
+        pred.grad = None
+        v = fn()
+        v.backward()
+        il_d[tag], il_d[tag + ".grad"] = np.float64(v.item()), _np(pred.grad)
+    save(os.path.join(out_dir, "image_losses.npz"), **il_d)
+
+    # one iteration of the reference training loop, executed from the text of render_surface.py:545-699
+    # (stage-2 settings: visibility rendering on, past every warm-up, edges on, smoothness loss on)
+    if not only or "train_step.npz" in only:
+        targs = Namespace(is_metal=False, smoothness_weight=1e-4, num_iters=12001, roughness_warmup_step=2000,
+                          indirect_warmup_step=10000, render_visibility=True, render_visibility_step=4001,
+                          render_brdf=False, patch_size=32, gamma_pred=False, eik_weight=0.1, ssim_weight=1.0,
+                          roughrange_weight=0.1)
+        ns2 = dict(torch=torch, nn=nn, F=F, np=np, dino_dimension=384, args=targs, ggx_renderer_modified=ggx)
+        exec("\n".join(lines[39:176]), ns2)
+        torch.manual_seed(61)
+        t_sdf = SDFNetwork(**SDF_FULL)
+        t_sdf.load_state_dict(net_edge.state_dict())
+        t_cnd = {k: RenderingNetwork(**v) for k, v in MAT.items()}
+        t_cnd["point_light_network"] = PointLightNetwork(enable_offset=True)
+        t_cnd["blend_network"] = BlendNetwork(**BLEND)
+        for k in MAT:
+            t_cnd[k].load_state_dict(cnd[k].state_dict())
+        t_cnd["blend_network"].load_state_dict(cnd["blend_network"].state_dict())
+        t_cnd["point_light_network"].set_light(135.0)
+        t_cnd["point_light_network"].light_offset.weight.data = torch.tensor([[0.2, 0.1, 0.05]])
+        t_dino = DINONetwork(**DINO)
+        t_dino.load_state_dict(dino_net.state_dict())
+        g = torch.Generator().manual_seed(62)
+        gt_images = torch.rand(2, 64, 64, 3, generator=g)
+        grad_images = [torch.rand(64, 64, generator=g) for _ in range(2)]
+        cams = [standard_camera(rt.Camera, 64, 64, roty=-0.6), standard_camera(rt.Camera, 64, 64, roty=0.9)]
+        sdf_opt = torch.optim.Adam(t_sdf.parameters(), lr=1e-5)
+        plp = [{"params": [t_cnd["point_light_network"].light], "lr": 2e-5},
+               {"params": list(t_cnd["point_light_network"].light_offset.parameters()), "lr": 1e-4}]
+        copt = {k: (torch.optim.Adam(plp) if k == "point_light_network" else torch.optim.Adam(v.parameters(), lr=1e-4))
+                for k, v in t_cnd.items()}
+        dino_opt = torch.optim.Adam(t_dino.parameters(), lr=1e-3)
+        tq = types.ModuleType("tqdm")
+        tq.tqdm = lambda it, **k: it
+        ns3 = dict(torch=torch, np=np, tqdm=tq, args=targs, start_step=11999, sdf_optimizer=sdf_opt,
+                   color_optimizer_dict=copt, dino_optimizer=dino_opt, gt_images=gt_images, grad_images=grad_images,
+                   cameras=cams, color_network_dict=t_cnd, sdf_network=t_sdf, raytracer=tracer, dino_network=t_dino,
+                   render_fn=ns2["render_fn"], render_camera=rt.render_camera, fill_holes=False, handle_edges=True,
+                   is_training=True, inv_s=inv_s, pyramidl2_loss_fn=pyr, ssim_loss_fn=il.ssim_loss_fn,
+                   ssim_weight=targs.ssim_weight, smoothness_weight=targs.smoothness_weight,
+                   roughrange_weight=targs.roughrange_weight, eik_weight=targs.eik_weight)
+        ts = dict(gt_images=_np(gt_images), grad_images=np.stack([_np(x) for x in grad_images]),
+                  K=np.stack([_np(c.K) for c in cams]), W2C=np.stack([_np(c.W2C) for c in cams]), inv_s=_np(inv_s),
+                  np_seed=71, torch_seed=72, global_step=12000)
+        ts.update(state_to_np("sdf.", t_sdf))
+        ts.update(state_to_np("mat.blend_network.", t_cnd["blend_network"]))
+        np.random.seed(71)
+        torch.manual_seed(72)
+        exec("\n".join(lines[544:699]), ns3)
+        torch.manual_seed(72)
+        ts["eik_points"] = _np(torch.empty(32 * 32 // 2, 3).float().uniform_(-1.0, 1.0))
+        for k in ("loss", "img_loss", "img_l1_loss", "img_l2_loss", "img_ssim_loss", "eik_loss", "roughrange_loss",
+                  "smoothness_loss"):
+            ts["out." + k] = np.float64(float(ns3[k].reshape(-1)[0]) if torch.is_tensor(ns3[k]) else float(ns3[k]))
+        ts["out.idx"] = ns3["idx"]
+        ts["out.K_crop"] = _np(ns3["camera_crop"].K)
+        ts["out.mask"], ts["out.edge_mask"] = _np(ns3["convergent_mask"]), _np(ns3["results"]["edge_mask"])
+        ts["out.color"] = _np(ns3["results"]["color"])
+        ts.update({"g.sdf." + k: v for k, v in grads_subsample(t_sdf.named_parameters()).items()})
+        for nm in list(MAT) + ["blend_network"]:
+            ts.update({f"g.{nm}." + k: v for k, v in grads_subsample(t_cnd[nm].named_parameters()).items()})
+        ts["g_light"] = _np(t_cnd["point_light_network"].light.grad)
+        ts["g_offset"] = _np(t_cnd["point_light_network"].light_offset.weight.grad)
+        # parameters after the optimizer schedule of this step (sdf + point light step; materials do not)
+        ts["after.light"] = _np(t_cnd["point_light_network"].light)
+        ts["after.offset"] = _np(t_cnd["point_light_network"].light_offset.weight)
+        ts["after.sdf.lin8.bias"] = _np(t_sdf.lin8.bias)
+        ts["after.sdf.lin2.weight_g"] = _np(t_sdf.lin2.weight_g)
+        ts["after.diffuse.lin0.bias"] = _np(t_cnd["diffuse_albedo_network"].lin0.bias)
+        print("train step: loss", ts["out.loss"], "hits", int(ts["out.mask"].sum()), "edges", int(ts["out.edge_mask"].sum()),
+              "smooth", ts["out.smoothness_loss"], "rough", ts["out.roughrange_loss"], "idx", ts["out.idx"])
+        save(os.path.join(out_dir, "train_step.npz"), **ts)
+
     # known-answer GGX cases of SURVEY.md Appendix A are asserted directly in the tests.
     tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
     print("wrote fixtures to", out_dir, "total bytes", tot)
