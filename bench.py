@@ -105,6 +105,9 @@ def main():
     ap.add_argument("--res", type=int, default=800)
     ap.add_argument("--cpu-res", type=int, default=80)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal "
+                                                      "of the multi-process path with every rank on one GPU)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,10 +115,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from pir_amd import _lib
     L = _lib.lib()
@@ -126,9 +134,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    say = (lambda m: print(f"[rank {rank}] {m}", file=sys.stderr, flush=True)) if args.one_device else (lambda m: None)
+    say("built")
     for _ in range(args.warmup):
         step()
+        say("warmup step done")
     barrier()
+    say("barrier passed")
     L.pir_profile_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -137,7 +149,7 @@ def main():
     dt = time.perf_counter() - t0
     L.pir_profile_enable(0)
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

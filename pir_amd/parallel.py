@@ -32,7 +32,12 @@ class FlatGradBucket:
             else:
                 v.copy_(p.grad)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.flat.is_cuda and dist.get_backend() == "gloo":   # CPU-staged rehearsal of the RCCL path
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             if average:
                 self.flat.div_(dist.get_world_size())
         for p, v in zip(self.params, self.views):
