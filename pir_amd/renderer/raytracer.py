@@ -661,3 +661,21 @@ def render_camera_visibility(camera, sdf_network, raytracer, fill_holes=True, ha
         render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_samples=256,
                                 max_num_pts=max_num_pts, is_training=is_training)
     return results
+
+
+def render_dino(results, dino_network, max_num_pts=320000, is_training=True):
+    """DINO field at the hit points, zero elsewhere -> results["dino"] [H, W, 384] (raytracer.py:1313-1352)."""
+    dots_sh = list(results["convergent_mask"].shape)
+    mask = results["convergent_mask"].reshape(-1)
+    dino = torch.zeros(mask.shape[0], dimension, dtype=torch.float32, device=mask.device)
+    if mask.any():
+        feat = dino_network(results["points"].reshape(-1, 3)[mask], is_training=is_training)
+        dino = dino.index_put((mask.nonzero(as_tuple=True)[0],), feat)
+    results.update({"dino": dino.reshape(dots_sh + [-1])})
+
+
+def dino_camera(camera, sdf_network, raytracer, dino_network, is_training=True):
+    """Trace the camera and evaluate the surface DINO feature (raytracer.py:1355-1379)."""
+    results = raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000)
+    render_dino(results, dino_network, max_num_pts=320000, is_training=is_training)
+    return results

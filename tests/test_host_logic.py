@@ -179,3 +179,16 @@ def test_training_step_matches_reference_on_cpu(tmp_path):
                                 state.color_network_dict) == 5000 and loader.path2step(path) == 5000
     assert np.array_equal(state.sdf_network.lin0.bias.detach().numpy(), d["sdf.lin0.bias"])
     assert loader.load_dino_ckpt([], state.dino_network) == -1
+
+
+def test_dino_camera_matches_oracle_field():
+    from oracle import pir_oracle as O
+    from pir_amd import scene
+    from pir_amd.renderer.raytracer import RayTracer, dino_camera
+    sdf, _, dino = scene.build_networks(seed=3)
+    cam = scene.make_camera(20, 20)
+    res = dino_camera(cam, sdf, RayTracer(), dino, is_training=False)
+    m = res["convergent_mask"]
+    ref = O.dino_mlp(O.mlp_layers(dict(dino.state_dict())), scene.MODEL_CONFIG["dino_network"], res["points"][m])
+    assert res["dino"].shape == (20, 20, 384) and not res["dino"].requires_grad
+    assert rel_err(res["dino"][m], ref.detach()) < 1e-5 and res["dino"][~m].abs().max() == 0
