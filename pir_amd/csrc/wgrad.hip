@@ -243,9 +243,6 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
     const int n_rows = (n + 31) / 32 * 32;
     int rc = pir_internal_bwd_sweep(packed, x, g_sdf, g_feat, g_normal, base, n, &sc, g_x, stream_);
     if (rc != PIR_OK) return rc;
-    // K slices of >= 8 staged steps each; many more workgroups than CUs so the dispatcher balances them
-    int ksplit = n_rows / kWgKPts / 8;
-    ksplit = ksplit < 1 ? 1 : (ksplit > kKSplitMax ? kKSplitMax : ksplit);
     WgJobs jobs;
     jobs.n = 0;
     for (int l = 0; l < 8; ++l) {
@@ -272,6 +269,19 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
           j.ldy = 256; j.x1_rows = n; j.o0 = 128 * ot; j.i0 = 128 * itl;
           j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.scale = 1.0f; j.bias = itl == 0;
         }
+    }
+    // K slices of >= 8 staged steps each, their number chosen so that the workgroups fill whole rounds of the
+    // 2-per-CU resident slots (30 jobs x 64 slices left the last round a quarter empty: -5.5 %)
+    int ksplit = 1;
+    {
+      const int kmax = n_rows / kWgKPts / 8 < kKSplitMax ? n_rows / kWgKPts / 8 : kKSplitMax;
+      const long slots = 2L * pir_num_cus();
+      double best = -1.0;
+      for (int k = 1; k <= kmax; ++k) {
+        const long wgs = (long)jobs.n * k, rounds = (wgs + slots - 1) / slots;
+        const double eff = (double)wgs / (double)(rounds * slots);
+        if (eff >= best - 1e-9) { best = eff; ksplit = k; }   // ties: the finer split
+      }
     }
     {
       PirProfScope prof(PIR_K_WGRAD, (double)n, stream_);
