@@ -192,3 +192,29 @@ def test_dino_camera_matches_oracle_field():
     ref = O.dino_mlp(O.mlp_layers(dict(dino.state_dict())), scene.MODEL_CONFIG["dino_network"], res["points"][m])
     assert res["dino"].shape == (20, 20, 384) and not res["dino"].requires_grad
     assert rel_err(res["dino"][m], ref.detach()) < 1e-5 and res["dino"][~m].abs().max() == 0
+
+
+def test_product_code_never_touches_the_oracle_or_the_reference():
+    """oracle/ is test infrastructure: nothing under pir_amd/ may import it, and nothing that runs on the GPU box
+    (package, bench, entry points, tests) may read the reference checkout."""
+    ref = "/root/" + "reference"
+    pkg = os.path.join(ROOT, "pir_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cuh", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), f
+                assert "pir_oracle" not in text, f
+                assert ref not in text, f
+    for f in ["bench.py", "__graft_entry__.py"] + [os.path.join("tests", t) for t in os.listdir(os.path.join(ROOT, "tests"))
+                                                   if t.endswith(".py")]:
+        text = open(os.path.join(ROOT, f)).read()
+        assert ref not in text, f
+
+
+def test_kernels_fail_loudly_without_the_library(monkeypatch):
+    from pir_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpir_hip.so")
+    with pytest.raises(_lib.PirHipError):
+        _lib.lib()
