@@ -103,7 +103,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--cpu-res", type=int, default=96)
+    ap.add_argument("--cpu-res", type=int, default=128,
+                    help="side of the view the CPU oracle renders for cpu_baseline (128: about 15-20 s on 16 threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal "
                                                       "of the multi-process path with every rank on one GPU)")
