@@ -121,13 +121,50 @@ int pir_ggx_backward(long P, const float* light, int light_is_rgb, int direct_ra
                      float* g_normal, float* g_lightdir, float* g_viewdir, float* g_kd, float* g_ks, float* g_alpha,
                      void* stream);
 
+/* ---- material / feature-field MLPs (src/network.py:146-267 RenderingNetwork, :382-467 DINONetwork, :295-367
+ *      BlendNetwork): ReLU MLPs with 256-wide hidden layers, the input optionally concatenated again at one skip
+ *      layer ([h | x] / sqrt 2, :237-238), linear output layer ------------------------------------------------ */
+
+/* Floats one packed product of n_kblocks k-blocks (8 input columns each) x 256 outputs occupies. */
+size_t pir_mlp_product_floats(int n_kblocks);
+
+/* Re-lay the block W[row0 : row0+nrows, col0 : col0+ncols] (row-major, leading dimension ld; nrows <= 256,
+ * ncols <= 8 n_kblocks, the rest is zero-filled) times `scale` into MFMA fragment order at dst.  transposed != 0
+ * packs the transpose of the block W[row0 : row0+ncols, col0 : col0+nrows] instead (the backward's W^T products).
+ * Replaces the per-call weight_norm + nn.Linear of the reference modules' forward (src/network.py:234-243). */
+int pir_mlp_pack_product(const float* W, int ld, int row0, int nrows, int col0, int ncols, int transposed, float scale,
+                         float* dst, int n_kblocks, void* stream);
+
+/* Layer plan of one packed network.  The packed buffer is [mats_floats floats of products | vectors]; prod_*
+ * are offsets in units of 4 floats into the products, *_off float offsets into the vectors. */
+typedef struct PirMlpPlan {
+  int kin_kb;        /* k-blocks of the zero-padded input: rows of X are 8 * kin_kb floats */
+  int n_hidden;      /* 256-wide ReLU layers, 1..8 */
+  int skip;          /* hidden layer (1..n_hidden-1) whose input is [h | x] / sqrt 2 (scale folded into the pack), or -1 */
+  int n_out;         /* outputs of the linear last layer (<= 4, or a multiple of 4) */
+  int prod_in;       /* lin0 over x: kin_kb k-blocks */
+  int prod_h[8];     /* hidden layer l over the previous activations: 32 k-blocks, l = 1..n_hidden-1 */
+  int prod_skip_x;   /* the skip layer over x: kin_kb k-blocks */
+  int prod_out;      /* output layer, ceil(n_out / 256) passes of 32 k-blocks (n_out > 4 only) */
+  int bias_off;      /* hidden biases [n_hidden][256] */
+  int head_off;      /* output-layer rows [n_out][256] (n_out <= 4 only) */
+  int out_bias_off;  /* output bias, padded to 4 floats or to 256 per pass */
+} PirMlpPlan;
+
+/* out [P, n_out] = last layer(relu(...relu(lin0 x)...)) for x [P, 8 kin_kb] (zero-padded input rows).
+ * RenderingNetwork.forward / DINONetwork.forward / BlendNetwork.forward up to, not including, the output
+ * transform (output_scale, output_bias, sigmoid; src/network.py:245-247), which stays a [P, n_out] PyTorch op. */
+int pir_mlp_forward(const void* packed, size_t mats_floats, const PirMlpPlan* plan, const float* X, long P, float* out,
+                    void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------------ */
 
 /* Kernel families timed by the optional HIP-event profiler. */
 enum { PIR_K_SDF_EVAL = 0, PIR_K_SDF_GETALL = 1, PIR_K_TRACE_STEP = 2, PIR_K_SAMPLER = 3, PIR_K_BISECT = 4,
        PIR_K_BWD_SWEEP = 5, PIR_K_WGRAD = 6, PIR_K_GGX_FWD = 7, PIR_K_GGX_BWD = 8,
        PIR_K_SDF_EVAL_FEAT = 9, PIR_K_SDF_GETALL_FEAT = 10,   /* the variants that also write the 256 features */
-       PIR_K_COUNT = 11 };
+       PIR_K_MLP_FWD = 11, PIR_K_MLP_BWD = 12,                /* material / feature-field MLP kernels */
+       PIR_K_COUNT = 13 };
 /* When enabled every kernel launch of the families above is bracketed by hipEvents on its stream. */
 int pir_profile_enable(int on);
 /* Synchronises and returns, per family id < n_ids, the number of launches, their summed duration (ms) and the

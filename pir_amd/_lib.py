@@ -68,6 +68,12 @@ def _declare(L):
     L.pir_visibility_forward.argtypes = [vp, vp, vp, vp, vp, lg, i32, vp, vp]
     L.pir_visibility_backward.restype = i32
     L.pir_visibility_backward.argtypes = [vp, vp, vp, vp, vp, vp, lg, i32, vp, vp, vp, vp, vp]
+    L.pir_mlp_product_floats.restype = sz
+    L.pir_mlp_product_floats.argtypes = [i32]
+    L.pir_mlp_pack_product.restype = i32
+    L.pir_mlp_pack_product.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp]
+    L.pir_mlp_forward.restype = i32
+    L.pir_mlp_forward.argtypes = [vp, sz, vp, vp, lg, vp, vp]
     L.pir_profile_enable.restype = i32
     L.pir_profile_enable.argtypes = [i32]
     L.pir_profile_read.restype = i32

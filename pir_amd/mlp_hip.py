@@ -1,0 +1,166 @@
+"""Host side of the fused ReLU-MLP kernels (csrc/mlp.hip): the material networks and the DINO feature field
+(reference: src/network.py:146-267 RenderingNetwork, :382-467 DINONetwork).
+
+A `PackedMlp` holds one network's effective (weight-normed) matrices in MFMA fragment order plus its bias / head
+vectors in ONE device buffer, and the layer plan the kernels read.  It is rebuilt whenever a parameter changed.
+"""
+import ctypes
+import math
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+_ACT_KB = 32            # k-blocks of a 256-wide activation
+_HIDDEN = 256
+
+
+class PirMlpPlan(ctypes.Structure):
+    """include/pir_hip.h: PirMlpPlan"""
+    _fields_ = [("kin_kb", ctypes.c_int), ("n_hidden", ctypes.c_int), ("skip", ctypes.c_int), ("n_out", ctypes.c_int),
+                ("prod_in", ctypes.c_int), ("prod_h", ctypes.c_int * 8), ("prod_skip_x", ctypes.c_int),
+                ("prod_out", ctypes.c_int), ("bias_off", ctypes.c_int), ("head_off", ctypes.c_int),
+                ("out_bias_off", ctypes.c_int)]
+
+
+def supported_shapes(shapes, skip: Optional[int]) -> bool:
+    """shapes: [(out, in)] of lin0..lin_last.  Hidden layers 256 wide, at most 8 of them, one optional skip layer."""
+    n_hidden = len(shapes) - 1
+    if not 1 <= n_hidden <= 8:
+        return False
+    k0 = shapes[0][1]
+    for l, (o, i) in enumerate(shapes[:-1]):
+        if o != _HIDDEN:
+            return False
+        want_in = k0 if l == 0 else (_HIDDEN + k0 if l == skip else _HIDDEN)
+        if i != want_in:
+            return False
+    n_out, last_in = shapes[-1]
+    if last_in != _HIDDEN or n_out < 1 or (n_out > 4 and n_out % 4):
+        return False
+    return skip is None or 1 <= skip < n_hidden
+
+
+class PackedMlp:
+    def __init__(self, weights: List[torch.Tensor], biases: List[torch.Tensor], skip: Optional[int] = None):
+        L = _lib.lib()
+        shapes = [tuple(w.shape) for w in weights]
+        assert supported_shapes(shapes, skip), f"unsupported MLP for the HIP path: {shapes}, skip {skip}"
+        dev = weights[0].device
+        assert dev.type == "cuda"
+        ws = [w.detach().contiguous().float() for w in weights]
+        bs = [b.detach().contiguous().float() for b in biases]
+        self.device = dev
+        self.k0 = shapes[0][1]
+        self.kin_kb = (self.k0 + 7) // 8
+        self.n_hidden = len(ws) - 1
+        self.n_out = shapes[-1][0]
+        self.skip = skip
+        per_kb = L.pir_mlp_product_floats(1)
+        # ---- layout of the product region (in floats)
+        off = 0
+        jobs = []          # (W, ld, row0, nrows, col0, ncols, transposed, scale, float offset, n_kblocks)
+        plan = PirMlpPlan()
+        plan.kin_kb, plan.n_hidden, plan.skip, plan.n_out = self.kin_kb, self.n_hidden, -1 if skip is None else skip, self.n_out
+        is2 = 1.0 / math.sqrt(2.0)
+
+        def add(W, row0, nrows, col0, ncols, transposed, scale, nkb):
+            nonlocal off
+            jobs.append((W, W.shape[1], row0, nrows, col0, ncols, transposed, scale, off, nkb))
+            start = off // 4
+            off += per_kb * nkb
+            return start
+
+        plan.prod_in = add(ws[0], 0, _HIDDEN, 0, self.k0, 0, 1.0, self.kin_kb)
+        for l in range(1, self.n_hidden):
+            sc = is2 if l == skip else 1.0
+            plan.prod_h[l] = add(ws[l], 0, _HIDDEN, 0, _HIDDEN, 0, sc, _ACT_KB)
+        if skip is not None:
+            plan.prod_skip_x = add(ws[skip], 0, _HIDDEN, _HIDDEN, self.k0, 0, is2, self.kin_kb)
+        passes = (self.n_out + 255) // 256
+        if self.n_out > 4:
+            plan.prod_out = off // 4
+            for p in range(passes):
+                add(ws[-1], 256 * p, min(256, self.n_out - 256 * p), 0, _HIDDEN, 0, 1.0, _ACT_KB)
+        self.mats_floats = off
+        # ---- vectors
+        voff = 0
+        plan.bias_off = voff
+        voff += 256 * self.n_hidden
+        if self.n_out <= 4:
+            plan.head_off = voff
+            voff += 256 * self.n_out
+        plan.out_bias_off = voff
+        voff += 4 if self.n_out <= 4 else 256 * passes
+        self.plan = plan
+        self.buf = torch.zeros(self.mats_floats + voff, dtype=torch.float32, device=dev)
+        vec = self.buf[self.mats_floats:]
+        for l in range(self.n_hidden):
+            vec[plan.bias_off + 256 * l: plan.bias_off + 256 * (l + 1)] = bs[l]
+        if self.n_out <= 4:
+            vec[plan.head_off: plan.head_off + 256 * self.n_out] = ws[-1].reshape(-1)
+        vec[plan.out_bias_off: plan.out_bias_off + self.n_out] = bs[-1]
+        with torch.cuda.device(dev):
+            for (W, ld, row0, nrows, col0, ncols, tr, sc, foff, nkb) in jobs:
+                dst = ctypes.c_void_p(self.buf.data_ptr() + 4 * foff)
+                _lib.check(L.pir_mlp_pack_product(_lib.ptr(W), ld, row0, nrows, col0, ncols, tr, sc, dst, nkb,
+                                                  _lib.stream_ptr()), "pir_mlp_pack_product")
+        self._keep = ws   # the pack kernels read them asynchronously
+
+    def pad_input(self, x: torch.Tensor) -> torch.Tensor:
+        """[P, k0] -> contiguous [P, 8 kin_kb] with zero columns appended."""
+        x = x.detach().reshape(-1, self.k0).float()
+        pad = 8 * self.kin_kb - self.k0
+        if pad:
+            x = torch.cat([x, x.new_zeros(x.shape[0], pad)], dim=-1)
+        return x.contiguous()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Pre-transform output [P, n_out] of the last linear layer for input rows x [P, k0]."""
+        xp = self.pad_input(x)
+        P = xp.shape[0]
+        out = torch.empty(P, self.n_out, dtype=torch.float32, device=xp.device)
+        with torch.cuda.device(xp.device):
+            _lib.check(_lib.lib().pir_mlp_forward(_lib.ptr(self.buf), self.mats_floats, ctypes.byref(self.plan),
+                                                  _lib.ptr(xp), P, _lib.ptr(out), _lib.stream_ptr()), "pir_mlp_forward")
+        return out
+
+
+def module_layers(mod):
+    return [getattr(mod, "lin" + str(l)) for l in range(mod.num_layers - 1)]
+
+
+def module_supported(mod) -> bool:
+    p = next(mod.parameters())
+    if not p.is_cuda or len(mod.skip_in) > 1:
+        return False
+    lins = module_layers(mod)
+    shapes = [tuple(l.weight_v.shape) if l.weight_norm else tuple(l.weight.shape) for l in lins]
+    return supported_shapes(shapes, mod.skip_in[0] if mod.skip_in else None)
+
+
+def packed_for(mod) -> PackedMlp:
+    """Packed weights of a RenderingNetwork / DINONetwork, rebuilt whenever a parameter changed."""
+    key = tuple((p.data_ptr(), p._version) for p in mod.parameters())
+    if getattr(mod, "_packed_mlp", None) is None or mod._packed_mlp_key != key:
+        with torch.no_grad():
+            lins = module_layers(mod)
+            mod._packed_mlp = PackedMlp([l.effective_weight() for l in lins], [l.bias for l in lins],
+                                        mod.skip_in[0] if mod.skip_in else None)
+        mod._packed_mlp_key = key
+    return mod._packed_mlp
+
+
+def mlp_apply(mod, inp):
+    """Differentiable evaluation (training): until the fused backward lands this is the eager expression."""
+    import numpy as np
+    import torch.nn.functional as F
+    x = inp
+    for l in range(mod.num_layers - 1):
+        if l in mod.skip_in:
+            x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
+        x = getattr(mod, "lin" + str(l))(x)
+        if l < mod.num_layers - 2:
+            x = F.relu(x)
+    return x

@@ -52,6 +52,30 @@ class WNLinear(nn.Module):
         return F.linear(x, self.effective_weight(), self.bias)
 
 
+def _relu_mlp(mod, inp, keep_graph=True):
+    """lin0..lin_last of a RenderingNetwork / BlendNetwork / DINONetwork on the concatenated input rows `inp`
+    ([..., k0]; skip layers read [x | inp] / sqrt 2, ReLU after all but the last layer; src/network.py:232-243).
+    On a GPU, for the 256-wide architectures of configs/model_config.json, all layers run in one fused HIP
+    kernel (pir_amd/csrc/mlp.hip); the eager expression below defines the result everywhere else.
+    keep_graph=False: the caller detaches the result (DINONetwork with is_training=False)."""
+    from . import mlp_hip
+    if inp.is_cuda and mlp_hip.module_supported(mod):
+        needs_grad = keep_graph and torch.is_grad_enabled() and (
+            inp.requires_grad or any(p.requires_grad for p in mod.parameters()))
+        if not needs_grad:
+            out = mlp_hip.packed_for(mod).forward(inp.reshape(-1, inp.shape[-1]))
+            return out.reshape(*inp.shape[:-1], out.shape[-1])
+        return mlp_hip.mlp_apply(mod, inp)
+    x = inp
+    for l in range(mod.num_layers - 1):
+        if l in mod.skip_in:
+            x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
+        x = getattr(mod, "lin" + str(l))(x)
+        if l < mod.num_layers - 2:
+            x = F.relu(x)
+    return x
+
+
 class SDFNetwork(nn.Module):
     def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(4,), multires=0, bias=0.5, scale=1,
                  geometric_init=True, weight_norm=True, inside_outside=False):
@@ -215,13 +239,7 @@ class RenderingNetwork(nn.Module):
             inp = torch.cat([points, normals, geo_f, semantic_f], dim=-1)
         else:
             raise ValueError(self.mode)
-        x = inp
-        for l in range(self.num_layers - 1):
-            if l in self.skip_in:
-                x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
-            x = getattr(self, "lin" + str(l))(x)
-            if l < self.num_layers - 2:
-                x = F.relu(x)
+        x = _relu_mlp(self, inp)
         x = self.output_scale * (x + self.output_bias)
         if self.squeeze_out:
             x = self.squeeze_out_scale * torch.sigmoid(x)
@@ -290,13 +308,7 @@ class BlendNetwork(nn.Module):
         if self.embedview_fn is not None:
             dot_n_wo = self.embedview_fn(dot_n_wo)
         inp = torch.cat([distance, roughness, dot_n_wo] + ([features] if features is not None else []), dim=-1)
-        x = inp
-        for l in range(self.num_layers - 1):
-            if l in self.skip_in:
-                x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
-            x = getattr(self, "lin" + str(l))(x)
-            if l < self.num_layers - 2:
-                x = F.relu(x)
+        x = _relu_mlp(self, inp)
         x = self.output_scale * (x + self.output_bias)
         if self.squeeze_out:
             return self.squeeze_out_scale * torch.sigmoid(x)
@@ -343,12 +355,6 @@ class DINONetwork(nn.Module):
             inp = torch.cat(parts, dim=-1)
         else:
             inp = points
-        x = inp
-        for l in range(self.num_layers - 1):
-            if l in self.skip_in:
-                x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
-            x = getattr(self, "lin" + str(l))(x)
-            if l < self.num_layers - 2:
-                x = F.relu(x)
+        x = _relu_mlp(self, inp, keep_graph=is_training)
         x = self.output_scale * (x + self.output_bias)
         return x if is_training else x.detach()

@@ -4,7 +4,7 @@ set -e
 name=$1; shift
 cd "$(dirname "$0")/.."
 mkdir -p variants/obj_$name
-for f in sdf_eval trace ggx sdf_backward wgrad visibility prof; do
+for f in sdf_eval trace ggx sdf_backward wgrad visibility mlp prof; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment "$@" -c pir_amd/csrc/$f.hip -o variants/obj_$name/$f.o &
 done
 wait
