@@ -155,14 +155,15 @@ def main():
         dt = float(t.item())
 
     n = _lib.lib().pir_profile_read
-    nk = 11
+    nk = 13
     launches = (ctypes.c_long * nk)()
     total_ms = (ctypes.c_double * nk)()
     units = (ctypes.c_double * nk)()
     n(nk, launches, total_ms, units)
     names = ["sdf_eval_kernel(forward)", "sdf_eval_kernel(get_all)", "trace_step_kernel", "sampler_kernel",
              "bisect_kernel", "bwd_sweep_kernel", "wgrad_kernel", "ggx_forward_kernel", "ggx_backward_kernel",
-             "sdf_eval_kernel(forward+features)", "sdf_eval_kernel(get_all+features)"]
+             "sdf_eval_kernel(forward+features)", "sdf_eval_kernel(get_all+features)", "mlp_eval_kernel",
+             "mlp_bwd_sweep_kernel+wgrad(materials)"]
     # algorithmic FLOP per unit (point): get_all = forward + reverse sweep; bwd sweep = dh chains of both passes
     # (2 x forward); wgrad = 2 products (2 x forward).  Visibility samples (no feature head) dominate the counts,
     # so the sdf-only forward figure is used for them.

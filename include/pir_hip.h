@@ -149,6 +149,11 @@ typedef struct PirMlpPlan {
   int bias_off;      /* hidden biases [n_hidden][256] */
   int head_off;      /* output-layer rows [n_out][256] (n_out <= 4 only) */
   int out_bias_off;  /* output bias, padded to 4 floats or to 256 per pass */
+  /* transposed products for pir_mlp_backward (has_bwd = 0: packed for inference only) */
+  int has_bwd;
+  int rprod_h[8];    /* W_l^T, l = 1..n_hidden-1: 32 k-blocks each */
+  int rprod_in;      /* W_0^T: ceil(kin_kb / 32) passes of 256 input columns x 32 k-blocks */
+  int rprod_skip_x;  /* the x part of the skip layer, transposed: same shape */
 } PirMlpPlan;
 
 /* out [P, n_out] = last layer(relu(...relu(lin0 x)...)) for x [P, 8 kin_kb] (zero-padded input rows).
@@ -156,6 +161,19 @@ typedef struct PirMlpPlan {
  * transform (output_scale, output_bias, sigmoid; src/network.py:245-247), which stays a [P, n_out] PyTorch op. */
 int pir_mlp_forward(const void* packed, size_t mats_floats, const PirMlpPlan* plan, const float* X, long P, float* out,
                     void* stream);
+
+/* Scratch bytes for pir_mlp_backward when it processes chunk_points points per pass (split-K slabs + the stored
+ * activations and pre-activation gradients, 2 KB per point and hidden layer). */
+size_t pir_mlp_backward_scratch_bytes(int n_hidden, long chunk_points);
+
+/* Backward of pir_mlp_forward (what autograd derives for src/network.py:232-243; n_out <= 4): given g_out [P, n_out]
+ * accumulates (+=) dL/dW_l into gw[l] (row-major, the true shapes [256, k0], [256, 256], [256, 256 + k0] for the
+ * skip layer, [n_out, 256]) and dL/db_l into gb[l], l = 0..n_hidden, and writes dL/dx into g_x [P, 8 kin_kb] if
+ * non-NULL.  gw / gb: HOST arrays of n_hidden + 1 device pointers, zero-initialised by the caller.  k0 = true input
+ * width.  Recomputes the activations (nothing is kept from the forward); deterministic (no float atomics). */
+int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* plan, int k0, const float* X, long P,
+                     const float* g_out, float* g_x, float* const* gw, float* const* gb, void* scratch,
+                     size_t scratch_bytes, void* stream);
 
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------------ */
 

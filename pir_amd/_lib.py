@@ -74,6 +74,10 @@ def _declare(L):
     L.pir_mlp_pack_product.argtypes = [vp, i32, i32, i32, i32, i32, i32, f32, vp, i32, vp]
     L.pir_mlp_forward.restype = i32
     L.pir_mlp_forward.argtypes = [vp, sz, vp, vp, lg, vp, vp]
+    L.pir_mlp_backward_scratch_bytes.restype = sz
+    L.pir_mlp_backward_scratch_bytes.argtypes = [i32, lg]
+    L.pir_mlp_backward.restype = i32
+    L.pir_mlp_backward.argtypes = [vp, sz, vp, i32, vp, lg, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, sz, vp]
     L.pir_profile_enable.restype = i32
     L.pir_profile_enable.argtypes = [i32]
     L.pir_profile_read.restype = i32

@@ -7,6 +7,7 @@
 // in slices of 256 columns.
 #include "sdf_core.cuh"
 #include "sdf_sweeps.cuh"
+#include "wgrad.h"
 #include "pir_common.h"
 #include <string.h>
 
@@ -38,6 +39,11 @@ struct MlpPlan {
   int bias_off;      // float offsets into the vector region: hidden biases [n_hidden][256]
   int head_off;      //   output rows [n_out][256] (n_out <= 4 only)
   int out_bias_off;  //   output bias, padded to 4 or to 256 * passes
+  // transposed products of the backward (0 when the network was packed for inference only)
+  int has_bwd;
+  int rprod_h[8];    //   W_l^T over the 256 outputs of hidden layer l (32 k-blocks), l = 1..n_hidden-1
+  int rprod_in;      //   W_0^T: ceil(kin_kb / 32) passes of 256 input columns, 32 k-blocks each
+  int rprod_skip_x;  //   the x part of the skip layer, transposed: same shape as rprod_in
 };
 
 // x-slice of both operand sets -> activation region, then acc += W[:, slice] x slice, for every slice of the input.
@@ -175,6 +181,175 @@ mlp_eval_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, 
   }
 }
 
+// ---- backward ------------------------------------------------------------------------------------------------
+// Per 64-point tile: recompute the hidden activations (stored to H_l for the weight-gradient GEMM), then
+//   dz_{L-1} = (W_out^T g_out) (.) [a_{L-1} > 0]            (n_out <= 4: a rank-n_out update on the VALU)
+//   dz_{l-1} = (W_l^T dz_l) (.) [a_{l-1} > 0]               (transposed products on MFMA)
+//   g_x      = W_0^T dz_0 (+ W_skip,x^T dz_skip)
+// dz_l goes to DZ_l ([row][256]); wgrad.hip then forms dW_l = DZ_l^T H_{l-1} (H_{-1} = x) and db_l.
+struct MlpBwdScratch { float* H; float* DZ; size_t stride; };   // layer l at + l * stride, [chunk rows][256]
+
+// acc (input-gradient tiles of one pass of 256 columns) -> g_x[P][8 kin_kb], optionally accumulating
+__device__ __forceinline__ void store_gx_pass(const f32x16 (&acc)[kSets][kTPW], float* __restrict__ g_x, int kin_kb,
+                                              int pass, long base, long P, bool accumulate) {
+  const int lane = lane_id(), w = wave_id(), j = lane & 31, h = lane >> 5;
+  const size_t ldx = (size_t)8 * kin_kb;
+#pragma unroll
+  for (int s = 0; s < kSets; ++s) {
+    const long Q = base + 32 * s + j;
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) {
+      const int T = kTPW * w + t;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = 256 * pass + 32 * T + 8 * g + 4 * h;
+        if (Q < P && col < (int)ldx) {
+          f32x4* dst = reinterpret_cast<f32x4*>(g_x + (size_t)Q * ldx + col);
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = acc[s][t][4 * g + c];
+          if (accumulate) { const f32x4 old = *dst; o += old; }
+          *dst = o;
+        }
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
+mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, MlpPlan pl,
+                     const float* __restrict__ X, const float* __restrict__ g_out, long chunk_base, int chunk_n,
+                     long P, MlpBwdScratch sc, float* __restrict__ g_x) {
+  __shared__ Lds lds;
+  const int lane = lane_id(), w = wave_id(), j = lane & 31, h = lane >> 5;
+  const int ntiles = (chunk_n + kWgPts - 1) / kWgPts;
+  const int L = pl.n_hidden;
+  const int xpasses = (pl.kin_kb + kActKB - 1) / kActKB;
+  const long chunk_end = chunk_base + chunk_n;
+  const long rpad = (long)ntiles * kWgPts;   // rows of the chunk's scratch arrays that this launch defines (zeros / finite
+                                             // values beyond chunk_n: the weight-gradient GEMM reads whole 32-row steps)
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long base = chunk_base + (long)tile * kWgPts;
+    const long row0 = (long)tile * kWgPts;
+    mlp_hidden<true>(lds, mats, vecs, pl, X, base, chunk_end, sc.H, sc.stride, row0, rpad);
+    // ---- output layer: dz_{L-1} from g_out, masked by the activations still in LDS
+    float go[kSets][4];
+#pragma unroll
+    for (int s = 0; s < kSets; ++s) {
+      const long Q = base + 32 * s + j;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) go[s][o] = (o < pl.n_out && Q < chunk_end) ? g_out[Q * pl.n_out + o] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < kTPW; ++t) {
+      const int T = kTPW * w + t;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 wv[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          wv[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (o < pl.n_out) wv[o] = load_feat4(vecs + pl.head_off + 256 * o, T, g, h);
+        }
+#pragma unroll
+        for (int s = 0; s < kSets; ++s) {
+          const f32x4 a = lds.act[s][4 * T + g][lane];
+          f32x4 dz;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float d = go[s][0] * wv[0][c] + go[s][1] * wv[1][c] + go[s][2] * wv[2][c] + go[s][3] * wv[3][c];
+            dz[c] = a[c] > 0.f ? d : 0.f;
+          }
+          lds.act[s][4 * T + g][lane] = dz;
+          const long r = row0 + 32 * s + j;
+          *reinterpret_cast<f32x4*>(sc.DZ + (size_t)(L - 1) * sc.stride + (size_t)r * 256 + 32 * T + 8 * g + 4 * h) = dz;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- hidden layers, last to first
+    f32x16 acc[kSets][kTPW];
+#pragma nounroll
+    for (int l = L - 1; l >= 1; --l) {
+      if (l == pl.skip && g_x) {   // the x share of the skip layer's input gradient
+        for (int p = 0; p < xpasses; ++p) {
+          zero_acc(acc);
+          gemm_phase<kTPW>(mats, Prod{pl.rprod_skip_x + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
+          store_gx_pass(acc, g_x, pl.kin_kb, p, base, chunk_end, false);
+        }
+      }
+      zero_acc(acc);
+      gemm_phase<kTPW>(mats, Prod{pl.rprod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
+      __syncthreads();   // every read of dz_l is done
+      const float* Hl = sc.H + (size_t)(l - 1) * sc.stride;
+      float* DZl = sc.DZ + (size_t)(l - 1) * sc.stride;
+#pragma unroll
+      for (int t = 0; t < kTPW; ++t) {
+        const int T = kTPW * w + t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int s = 0; s < kSets; ++s) {
+            const long r = row0 + 32 * s + j;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Hl + (size_t)r * 256 + 32 * T + 8 * g + 4 * h);
+            f32x4 dz;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dz[c] = a[c] > 0.f ? acc[s][t][4 * g + c] : 0.f;
+            lds.act[s][4 * T + g][lane] = dz;
+            *reinterpret_cast<f32x4*>(DZl + (size_t)r * 256 + 32 * T + 8 * g + 4 * h) = dz;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- input gradient of lin0
+    if (g_x) {
+      for (int p = 0; p < xpasses; ++p) {
+        zero_acc(acc);
+        gemm_phase<kTPW>(mats, Prod{pl.rprod_in + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
+        store_gx_pass(acc, g_x, pl.kin_kb, p, base, chunk_end, pl.skip >= 1);
+      }
+    }
+    // the next tile's first slice load synchronises before the activation region is overwritten
+  }
+}
+
+// dW_out[o][f] += sum_p g_out[p][o] a_{L-1}[p][f],  db_out[o] += sum_p g_out[p][o]   (n_out <= 4)
+constexpr int kHeadBlocks = 512;
+__global__ void __launch_bounds__(256)
+mlp_head_grad_kernel(const float* __restrict__ H, const float* __restrict__ g_out /* chunk-local */, int n_out, int chunk_n,
+                     float* __restrict__ partial /* [blocks][4][257] */) {
+  const int col = threadIdx.x;
+  const int r0 = (int)((long)blockIdx.x * chunk_n / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * chunk_n / gridDim.x);
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    const float a = H[(size_t)r * 256 + col];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      const float g = o < n_out ? g_out[(size_t)r * n_out + o] : 0.f;
+      s[o] += g * a;
+      sg[o] += g;
+    }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    partial[((size_t)blockIdx.x * 4 + o) * 257 + col] = s[o];
+    if (col == 0) partial[((size_t)blockIdx.x * 4 + o) * 257 + 256] = sg[o];
+  }
+}
+__global__ void __launch_bounds__(256)
+mlp_head_reduce_kernel(const float* __restrict__ partial, int n_out, float* __restrict__ gw, float* __restrict__ gb) {
+  const int o = blockIdx.x, col = threadIdx.x;
+  if (o >= n_out) return;
+  float s = 0.f, sg = 0.f;
+  for (int b = 0; b < kHeadBlocks; ++b) {
+    s += partial[((size_t)b * 4 + o) * 257 + col];
+    if (col == 0) sg += partial[((size_t)b * 4 + o) * 257 + 256];
+  }
+  gw[o * 256 + col] += s;
+  if (col == 0) gb[o] += sg;
+}
+
 static bool plan_ok(const MlpPlan& pl) {
   if (pl.kin_kb < 1 || pl.n_hidden < 1 || pl.n_hidden > 8 || pl.n_out < 1) return false;
   if (pl.skip != -1 && (pl.skip < 1 || pl.skip >= pl.n_hidden)) return false;
@@ -217,6 +392,94 @@ int pir_mlp_forward(const void* packed, size_t mats_floats, const PirMlpPlan* pl
   hipLaunchKernelGGL(mlp_eval_kernel, dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(kThreads), 0,
                      (hipStream_t)stream, mats, vecs, pl, X, P, out);
   return pir_check_launch();
+}
+
+size_t pir_mlp_backward_scratch_bytes(int n_hidden, long chunk_points) {
+  const size_t rows = (size_t)((chunk_points + 63) / 64) * 64;
+  return wgrad_fixed_bytes() + (size_t)kHeadBlocks * 4 * 257 * 4 + 512 + rows * (size_t)n_hidden * 2 * 1024;
+}
+
+int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* plan, int k0, const float* X, long P,
+                     const float* g_out, float* g_x, float* const* gw, float* const* gb, void* scratch,
+                     size_t scratch_bytes, void* stream_) {
+  if (!packed || !plan || P < 0 || (mats_floats & 3) || !gw || !gb) return PIR_ERR_ARG;
+  MlpPlan pl;
+  memcpy(&pl, plan, sizeof(pl));
+  if (!plan_ok(pl) || !pl.has_bwd || pl.n_out > 4 || k0 < 1 || k0 > 8 * pl.kin_kb) return PIR_ERR_ARG;
+  if (P == 0) return PIR_OK;
+  if (!X || !g_out || !scratch) return PIR_ERR_ARG;
+  const int L = pl.n_hidden;
+  GradOut out;
+  for (int l = 0; l < 9; ++l) { out.w[l] = l <= L ? gw[l] : nullptr; out.b[l] = l <= L ? gb[l] : nullptr; }
+  for (int l = 0; l <= L; ++l) if (!out.w[l] || !out.b[l]) return PIR_ERR_ARG;
+  const size_t head_bytes = ((size_t)kHeadBlocks * 4 * 257 * 4 + 255) & ~(size_t)255;
+  const size_t row_bytes = (size_t)L * 2 * 1024;
+  if (scratch_bytes < wgrad_fixed_bytes() + head_bytes + 256 + 64 * row_bytes) return PIR_ERR_SCRATCH;
+  long cap = (long)((scratch_bytes - wgrad_fixed_bytes() - head_bytes - 256) / row_bytes) / 64 * 64;
+  if (cap > 262144) cap = 262144;
+  const WgFixed fx = wgrad_carve(scratch);
+  float* head_partial = (float*)fx.rest;
+  MlpBwdScratch sc;
+  sc.stride = (size_t)cap * 256;
+  sc.H = (float*)(fx.rest + head_bytes);
+  sc.DZ = sc.H + (size_t)L * sc.stride;
+  const f32x4* mats = (const f32x4*)packed;
+  const float* vecs = (const float*)packed + mats_floats;
+  const int kpad = 8 * pl.kin_kb;
+  const float is2 = 0.70710678118654752440f;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (long base = 0; base < P; base += cap) {
+    const int n = (int)(P - base < cap ? P - base : cap);
+    const int n_rows = (n + 31) / 32 * 32;
+    const int ntiles = (n + kWgPts - 1) / kWgPts;
+    const long resident = 2L * pir_num_cus();
+    {
+      PirProfScope prof(PIR_K_MLP_BWD, (double)n, stream_);
+      hipLaunchKernelGGL(mlp_bwd_sweep_kernel, dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(kThreads), 0,
+                         stream, mats, vecs, pl, X, g_out, base, n, P, sc, g_x);
+    }
+    int rc = pir_check_launch();
+    if (rc != PIR_OK) return rc;
+    // weight-gradient jobs: dW_l = DZ_l^T [H_{l-1} | x], db_l = column sums of DZ_l
+    WgJobs jobs;
+    jobs.n = 0;
+    auto flush = [&]() -> int {
+      if (jobs.n == 0) return PIR_OK;
+      const int r = wgrad_run(jobs, n_rows, n, fx, nullptr, out, PIR_K_MLP_BWD, stream_);
+      jobs.n = 0;
+      return r;
+    };
+    auto add = [&](int l, const float* Y, int ldy, int y_rows, int ncols_y, int dest_cols, int col_off, float scale,
+                   bool with_bias) -> int {
+      for (int ot = 0; ot < 2; ++ot)
+        for (int i0 = 0; i0 < ncols_y; i0 += 128) {
+          if (jobs.n == kMaxJobs) { const int r = flush(); if (r != PIR_OK) return r; }
+          WgJob& j = jobs.j[jobs.n++];
+          j.X1 = sc.DZ + (size_t)l * sc.stride; j.X2 = nullptr; j.Y1 = Y; j.Y2 = nullptr;
+          j.ldy = ldy; j.x1_rows = -1; j.y1_rows = y_rows;
+          j.o0 = 128 * ot; j.i0 = i0;
+          j.layer = l; j.row_off = 0; j.rows = 256; j.cols = dest_cols; j.col_off = col_off; j.i_limit = ncols_y;
+          j.scale = scale; j.bias = with_bias && i0 == 0;
+        }
+      return PIR_OK;
+    };
+    const float* Xc = X + (size_t)base * kpad;
+    rc = add(0, Xc, kpad, n, k0, k0, 0, 1.0f, true);
+    for (int l = 1; l < L && rc == PIR_OK; ++l) {
+      const bool sk = l == pl.skip;
+      rc = add(l, sc.H + (size_t)(l - 1) * sc.stride, 256, -1, 256, sk ? 256 + k0 : 256, 0, sk ? is2 : 1.0f, true);
+      if (rc == PIR_OK && sk) rc = add(l, Xc, kpad, n, k0, 256 + k0, 256, is2, false);
+    }
+    if (rc == PIR_OK) rc = flush();
+    if (rc != PIR_OK) return rc;
+    hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(kHeadBlocks), dim3(256), 0, stream, sc.H + (size_t)(L - 1) * sc.stride,
+                       g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
+    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
+                       out.b[L]);
+    rc = pir_check_launch();
+    if (rc != PIR_OK) return rc;
+  }
+  return PIR_OK;
 }
 
 }  // extern "C"

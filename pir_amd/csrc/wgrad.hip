@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "sdf_core.cuh"
 #include "sdf_backward.h"
+#include "wgrad.h"
 #include "pir_common.h"
 
 namespace pir {
@@ -12,20 +13,6 @@ namespace pir {
 constexpr int kWgThreads = 256;
 constexpr int kWgTile = 128;     // C tile edge
 constexpr int kWgKPts = 32;      // points per K step staged in LDS
-constexpr int kMaxJobs = 40;
-constexpr int kKSplitMax = 64;
-
-struct WgJob {
-  const float* X1; const float* Y1;   // product 1 (Zb, H)
-  const float* X2; const float* Y2;   // product 2 (Q, Pb) or null
-  int ldy;                            // 256, or 64 for the encoding arrays
-  int x1_rows;                        // rows of X1 that exist (caller-owned g_feat is not padded); <0: all
-  int o0, i0;                         // C tile origin
-  int layer, row_off, rows, cols;     // destination: gW[layer][(row_off + o) * cols + i], o < rows
-  float scale;
-  int bias;                           // 1: this job also produces column sums of X1 (i0 == 0 jobs)
-};
-struct WgJobs { WgJob j[kMaxJobs]; int n; };
 
 struct TileRegs { f32x4 v[4]; };
 
@@ -79,7 +66,7 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __
   auto fetch = [&](int step) {
     const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts;
     load_tile(tx, prod ? jb.X2 : jb.X1, 256, jb.o0, row0, prod ? -1 : jb.x1_rows);
-    load_tile(ty, prod ? jb.Y2 : jb.Y1, jb.ldy, jb.i0, row0, -1);
+    load_tile(ty, prod ? jb.Y2 : jb.Y1, jb.ldy, jb.i0, row0, prod ? -1 : jb.y1_rows);
   };
   if (nsteps > 0) fetch(0);
   for (int step = 0; step < nsteps; ++step) {
@@ -157,14 +144,13 @@ row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const f
   if (col == 0) partial[blockIdx.x * 257 + 256] = sg;
 }
 
-struct GradOut { float* w[9]; float* b[9]; };
 
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
                     const float* __restrict__ row0_partial, GradOut out) {
   constexpr int kParts = 16;   // blocks per C tile (1024 elements each)
   const int job_id = blockIdx.x / kParts, part = blockIdx.x % kParts;
-  if (job_id == jobs.n) {   // the row-0 blocks: 257 columns over kParts blocks
+  if (job_id == jobs.n) {   // the row-0 blocks (SDF only; launched only when row0_partial is given): 257 columns
     for (int col = part * 256 + threadIdx.x; col < 257; col += kParts * 256) {
       float s = 0.f;
       for (int b = 0; b < kRow0Blocks; ++b) s += row0_partial[b * 257 + col];
@@ -177,10 +163,10 @@ wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, co
   const float* base = slabs + (size_t)job_id * kWgTile * kWgTile;
   for (int e = part * (kWgTile * kWgTile / kParts) + threadIdx.x; e < (part + 1) * (kWgTile * kWgTile / kParts); e += 256) {
     const int o = jb.o0 + e / kWgTile, i = jb.i0 + e % kWgTile;
-    if (o >= jb.rows || i >= jb.cols) continue;
+    if (o >= jb.rows || i >= jb.i_limit) continue;
     float s = 0.f;
     for (int k = 0; k < ksplit; ++k) s += base[k * stride + e];
-    out.w[jb.layer][(size_t)(jb.row_off + o) * jb.cols + i] += jb.scale * s;
+    out.w[jb.layer][(size_t)(jb.row_off + o) * jb.cols + jb.col_off + i] += jb.scale * s;
   }
   if (jb.bias && part == 0 && threadIdx.x < kWgTile) {
     const int o = jb.o0 + threadIdx.x;
@@ -198,6 +184,45 @@ constexpr size_t kBiasSlabBytes = (size_t)kKSplitMax * kMaxJobs * kWgTile * 4;
 constexpr size_t kRow0Bytes = (size_t)kRow0Blocks * 257 * 4;
 constexpr size_t kFixedBytes = ((kSlabBytes + 255) & ~(size_t)255) + ((kBiasSlabBytes + 255) & ~(size_t)255) +
                                ((kRow0Bytes + 255) & ~(size_t)255);
+
+size_t wgrad_fixed_bytes() { return kFixedBytes; }
+
+WgFixed wgrad_carve(void* scratch) {
+  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+  WgFixed fx;
+  fx.slabs = (float*)p; p += al256(kSlabBytes);
+  fx.bias_slabs = (float*)p; p += al256(kBiasSlabBytes);
+  fx.row0 = (float*)p; p += al256(kRow0Bytes);
+  fx.rest = p;
+  return fx;
+}
+
+int wgrad_run(const WgJobs& jobs, int n_rows, int n_points, const WgFixed& fx, const float* row0_partial,
+              const GradOut& out, int prof_id, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (jobs.n < 1 || jobs.n > kMaxJobs || n_rows < kWgKPts || (n_rows % kWgKPts)) return PIR_ERR_ARG;
+  // K slices of >= 8 staged steps each, their number chosen so that the workgroups fill whole rounds of the
+  // 2-per-CU resident slots (30 jobs x 64 slices left the last round a quarter empty: -5.5 %)
+  int ksplit = 1;
+  {
+    const int kmax = n_rows / kWgKPts / 8 < kKSplitMax ? n_rows / kWgKPts / 8 : kKSplitMax;
+    const long slots = 2L * pir_num_cus();
+    double best = -1.0;
+    for (int k = 1; k <= kmax; ++k) {
+      const long wgs = (long)jobs.n * k, rounds = (wgs + slots - 1) / slots;
+      const double eff = (double)wgs / (double)(rounds * slots);
+      if (eff >= best - 1e-9) { best = eff; ksplit = k; }   // ties: the finer split
+    }
+  }
+  {
+    PirProfScope prof(prof_id, (double)n_points, stream_);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * ksplit), dim3(kWgThreads), 0, stream, jobs, n_rows, ksplit,
+                       fx.slabs, fx.bias_slabs);
+  }
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((jobs.n + (row0_partial ? 1 : 0)) * 16), dim3(256), 0, stream, jobs,
+                     ksplit, fx.slabs, fx.bias_slabs, row0_partial, out);
+  return pir_check_launch();
+}
 
 }  // namespace pir
 
@@ -220,10 +245,10 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
   hipStream_t stream = (hipStream_t)stream_;
   long cap = (long)((scratch_bytes - kFixedBytes - 256) / kBwdRowBytes) / 32 * 32;
   if (cap > 262144) cap = 262144;
-  char* p = (char*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
-  float* slabs = (float*)p; p += al256(kSlabBytes);
-  float* bias_slabs = (float*)p; p += al256(kBiasSlabBytes);
-  float* row0 = (float*)p; p += al256(kRow0Bytes);
+  const WgFixed fx = wgrad_carve(scratch);
+  float* slabs = fx.slabs;
+  float* row0 = fx.row0;
+  char* p = fx.rest;
   BwdScratch sc;
   float* f = (float*)p;
   sc.layer_stride = (size_t)cap * 256;
@@ -254,9 +279,9 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
           j.Y1 = l == 0 ? sc.E : sc.A(l - 1);
           j.Y2 = l == 0 ? sc.Ed : sc.Ad(l - 1);
           j.ldy = l == 0 ? 64 : 256;
-          j.x1_rows = -1;
+          j.x1_rows = -1; j.y1_rows = -1;
           j.o0 = 128 * ot; j.i0 = 128 * itl;
-          j.layer = l; j.row_off = 0; j.rows = rows[l]; j.cols = cols[l];
+          j.layer = l; j.row_off = 0; j.rows = rows[l]; j.cols = cols[l]; j.col_off = 0; j.i_limit = cols[l];
           j.scale = l == 4 ? 0.70710678118654752440f : 1.0f;
           j.bias = itl == 0;
         }
@@ -266,32 +291,14 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
         for (int itl = 0; itl < 2; ++itl) {
           WgJob& j = jobs.j[jobs.n++];
           j.X1 = g_feat + (size_t)base * 256; j.X2 = nullptr; j.Y1 = sc.A(7); j.Y2 = nullptr;
-          j.ldy = 256; j.x1_rows = n; j.o0 = 128 * ot; j.i0 = 128 * itl;
-          j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.scale = 1.0f; j.bias = itl == 0;
+          j.ldy = 256; j.x1_rows = n; j.y1_rows = -1; j.o0 = 128 * ot; j.i0 = 128 * itl;
+          j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.col_off = 0; j.i_limit = 256; j.scale = 1.0f; j.bias = itl == 0;
         }
-    }
-    // K slices of >= 8 staged steps each, their number chosen so that the workgroups fill whole rounds of the
-    // 2-per-CU resident slots (30 jobs x 64 slices left the last round a quarter empty: -5.5 %)
-    int ksplit = 1;
-    {
-      const int kmax = n_rows / kWgKPts / 8 < kKSplitMax ? n_rows / kWgKPts / 8 : kKSplitMax;
-      const long slots = 2L * pir_num_cus();
-      double best = -1.0;
-      for (int k = 1; k <= kmax; ++k) {
-        const long wgs = (long)jobs.n * k, rounds = (wgs + slots - 1) / slots;
-        const double eff = (double)wgs / (double)(rounds * slots);
-        if (eff >= best - 1e-9) { best = eff; ksplit = k; }   // ties: the finer split
-      }
-    }
-    {
-      PirProfScope prof(PIR_K_WGRAD, (double)n, stream_);
-      hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * ksplit), dim3(kWgThreads), 0, stream, jobs, n_rows, ksplit,
-                         slabs, bias_slabs);
     }
     hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
                        g_sdf ? g_sdf + base : nullptr, n, row0);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((jobs.n + 1) * 16), dim3(256), 0, stream, jobs, ksplit, slabs, bias_slabs,
-                       row0, out);
+    rc = wgrad_run(jobs, n_rows, n, fx, row0, out, PIR_K_WGRAD, stream_);
+    if (rc != PIR_OK) return rc;
     rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
   }

@@ -21,7 +21,8 @@ class PirMlpPlan(ctypes.Structure):
     _fields_ = [("kin_kb", ctypes.c_int), ("n_hidden", ctypes.c_int), ("skip", ctypes.c_int), ("n_out", ctypes.c_int),
                 ("prod_in", ctypes.c_int), ("prod_h", ctypes.c_int * 8), ("prod_skip_x", ctypes.c_int),
                 ("prod_out", ctypes.c_int), ("bias_off", ctypes.c_int), ("head_off", ctypes.c_int),
-                ("out_bias_off", ctypes.c_int)]
+                ("out_bias_off", ctypes.c_int), ("has_bwd", ctypes.c_int), ("rprod_h", ctypes.c_int * 8),
+                ("rprod_in", ctypes.c_int), ("rprod_skip_x", ctypes.c_int)]
 
 
 def supported_shapes(shapes, skip: Optional[int]) -> bool:
@@ -83,6 +84,20 @@ class PackedMlp:
             plan.prod_out = off // 4
             for p in range(passes):
                 add(ws[-1], 256 * p, min(256, self.n_out - 256 * p), 0, _HIDDEN, 0, 1.0, _ACT_KB)
+        # transposed products of the backward (networks with a VALU head only: the DINO field is never trained
+        # through this path, render_surface.py:549,686-699)
+        plan.has_bwd = 1 if self.n_out <= 4 else 0
+        if plan.has_bwd:
+            xpasses = (self.kin_kb + _ACT_KB - 1) // _ACT_KB
+            for l in range(1, self.n_hidden):
+                plan.rprod_h[l] = add(ws[l], 0, _HIDDEN, 0, _HIDDEN, 1, is2 if l == skip else 1.0, _ACT_KB)
+            plan.rprod_in = off // 4
+            for p in range(xpasses):
+                add(ws[0], 0, min(256, self.k0 - 256 * p), 256 * p, _HIDDEN, 1, 1.0, _ACT_KB)
+            if skip is not None:
+                plan.rprod_skip_x = off // 4
+                for p in range(xpasses):
+                    add(ws[skip], 0, min(256, self.k0 - 256 * p), _HIDDEN + 256 * p, _HIDDEN, 1, is2, _ACT_KB)
         self.mats_floats = off
         # ---- vectors
         voff = 0
@@ -118,7 +133,9 @@ class PackedMlp:
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """Pre-transform output [P, n_out] of the last linear layer for input rows x [P, k0]."""
-        xp = self.pad_input(x)
+        return self.forward_padded(self.pad_input(x))
+
+    def forward_padded(self, xp: torch.Tensor) -> torch.Tensor:
         P = xp.shape[0]
         out = torch.empty(P, self.n_out, dtype=torch.float32, device=xp.device)
         with torch.cuda.device(xp.device):
@@ -133,7 +150,7 @@ def module_layers(mod):
 
 def module_supported(mod) -> bool:
     p = next(mod.parameters())
-    if not p.is_cuda or len(mod.skip_in) > 1:
+    if not p.is_cuda or p.dtype != torch.float32 or len(mod.skip_in) > 1:
         return False
     lins = module_layers(mod)
     shapes = [tuple(l.weight_v.shape) if l.weight_norm else tuple(l.weight.shape) for l in lins]
@@ -152,8 +169,9 @@ def packed_for(mod) -> PackedMlp:
     return mod._packed_mlp
 
 
-def mlp_apply(mod, inp):
-    """Differentiable evaluation (training): until the fused backward lands this is the eager expression."""
+def mlp_apply_eager(mod, inp):
+    """The eager PyTorch expression (rocBLAS GEMMs): the definition of the result, used for double-backward
+    (the smoothness loss differentiates d material / d points once more, render_surface.py:40-48,76-78)."""
     import numpy as np
     import torch.nn.functional as F
     x = inp
@@ -164,3 +182,91 @@ def mlp_apply(mod, inp):
         if l < mod.num_layers - 2:
             x = F.relu(x)
     return x
+
+
+_bwd_scratch_cache = {}
+BWD_CHUNK_POINTS = 131072
+_force_eager = 0
+
+
+class eager_grad:
+    """Context manager: differentiable evaluations inside use the eager expression (needed when the caller will
+    differentiate the result twice; the fused backward is once-differentiable)."""
+
+    def __enter__(self):
+        global _force_eager
+        _force_eager += 1
+
+    def __exit__(self, *exc):
+        global _force_eager
+        _force_eager -= 1
+        return False
+
+
+def _backward_scratch(device, n_hidden):
+    key = (torch.device(device).index, n_hidden)
+    buf = _bwd_scratch_cache.get(key)
+    if buf is None:
+        # the SDF backward's buffer is larger than any material network needs: share it when it exists
+        from . import sdf_hip
+        need = _lib.lib().pir_mlp_backward_scratch_bytes(n_hidden, BWD_CHUNK_POINTS)
+        for (idx, _), b in sdf_hip._bwd_scratch_cache.items():
+            if idx == torch.device(device).index and b.numel() >= need:
+                buf = b
+                break
+        if buf is None:
+            buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _bwd_scratch_cache[key] = buf
+    return buf
+
+
+class _MlpFn(torch.autograd.Function):
+    """out = fused MLP(inp) on the packed effective weights; backward = pir_mlp_backward (recompute + sweeps +
+    split-K weight-gradient GEMM).  PyTorch chains dW_l -> (weight_g, weight_v) through torch._weight_norm."""
+
+    @staticmethod
+    def forward(ctx, mod, inp, *wb):
+        packed = packed_for(mod)
+        x2 = inp.reshape(-1, inp.shape[-1])
+        xp = packed.pad_input(x2)
+        out = packed.forward_padded(xp)
+        ctx.packed, ctx.xp, ctx.in_shape = packed, xp, inp.shape
+        ctx.need_gx = inp.requires_grad
+        ctx.shapes = [tuple(t.shape) for t in wb]
+        return out.reshape(*inp.shape[:-1], out.shape[-1])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_out):
+        packed, xp = ctx.packed, ctx.xp
+        P = xp.shape[0]
+        dev = xp.device
+        nl = packed.n_hidden + 1
+        gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes[:nl]]
+        gbs = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes[nl:]]
+        gx = torch.empty(P, xp.shape[1], dtype=torch.float32, device=dev) if ctx.need_gx else None
+        g = g_out.detach().reshape(P, packed.n_out).contiguous().float()
+        scratch = _backward_scratch(dev, packed.n_hidden)
+        wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
+        bp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gbs])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().pir_mlp_backward(
+                _lib.ptr(packed.buf), packed.mats_floats, ctypes.byref(packed.plan), packed.k0, _lib.ptr(xp), P,
+                _lib.ptr(g), _lib.ptr(gx), wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()),
+                "pir_mlp_backward")
+        g_in = gx[:, :packed.k0].reshape(ctx.in_shape) if ctx.need_gx else None
+        return (None, g_in, *gws, *gbs)
+
+
+def mlp_apply_fused(mod, inp):
+    lins = module_layers(mod)
+    wb = [l.effective_weight() for l in lins] + [l.bias for l in lins]
+    return _MlpFn.apply(mod, inp, *wb)
+
+
+def mlp_apply(mod, inp):
+    """Differentiable evaluation: the fused kernels when the network has a fused backward (<= 4 outputs) and the
+    caller has not asked for the twice-differentiable eager expression."""
+    if _force_eager or packed_for(mod).plan.has_bwd == 0:
+        return mlp_apply_eager(mod, inp)
+    return mlp_apply_fused(mod, inp)
