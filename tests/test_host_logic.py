@@ -223,3 +223,36 @@ def test_kernels_fail_loudly_without_the_library(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpir_hip.so")
     with pytest.raises(_lib.PirHipError):
         _lib.lib()
+
+
+def test_full_size_material_networks_match_reference_on_cpu():
+    """Eager modules and the oracle against the reference's own RenderingNetwork / DINONetwork at the
+    configs/model_config.json sizes (tests/golden/materials_full.npz, weights from tests/materials_util.py)."""
+    import materials_util as MU
+    from oracle import pir_oracle as O
+    from pir_amd import scene
+    from pir_amd.network import RenderingNetwork, DINONetwork
+    d = load_golden("materials_full.npz")
+    pts, nrm, geo, dino = (torch.from_numpy(a) for a in MU.inputs(int(d["P"]), int(d["input_seed"])))
+    for name in MU.NAMES:
+        cfg = scene.MODEL_CONFIG[name]
+        net = (DINONetwork if name == "dino_network" else RenderingNetwork)(**cfg)
+        net.load_state_dict(MU.fill_state(net.state_dict(), int(d[f"{name}.weight_seed"])))
+        chk = float(sum(v.double().abs().sum() for v in net.state_dict().values()))
+        assert abs(chk - float(d[f"{name}.weight_checksum"])) < 1e-6 * chk     # same weights as the generator's
+        leaves = [t.clone().requires_grad_(True) for t in (pts, nrm, geo, dino)]
+        y = net(leaves[0], is_training=True) if name == "dino_network" else MU.call(net, name, *leaves)
+        assert rel_err(y.detach(), d[f"{name}.out"]) < 1e-5, name
+        (y * torch.from_numpy(d[f"{name}.cw"])).sum().backward()
+        for nm, t in zip(("pts", "nrm", "geo", "dino"), leaves):
+            if f"{name}.g_{nm}" in d.files:
+                assert rel_err(t.grad, d[f"{name}.g_{nm}"]) < 1e-4, (name, nm)
+        for k, p in net.named_parameters():
+            ref = d[f"{name}.g.{k}"]
+            g = p.grad.numpy()
+            assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 1e-4, (name, k)
+        layers = O.mlp_layers({k: v.detach() for k, v in net.state_dict().items()})
+        with torch.no_grad():
+            yo = O.dino_mlp(layers, cfg, pts) if name == "dino_network" else \
+                O.rendering_mlp(layers, cfg, pts, nrm, -nrm if name == "diffuse_albedo_network" else None, geo, dino)
+        assert rel_err(yo, d[f"{name}.out"]) < 1e-5, name
