@@ -175,6 +175,15 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
                      const float* g_out, float* g_x, float* const* gw, float* const* gb, void* scratch,
                      size_t scratch_bytes, void* stream);
 
+/* Second-order backward: what autograd derives when g_x of pir_mlp_backward is itself differentiated (the
+ * smoothness loss on d material / d points, render_surface.py:40-48,76-78, :669-672).  Given the upstream gradient
+ * gbar_x [P, 8 kin_kb] of g_x: accumulates (+=) d<gbar_x, g_x>/dW_l into gw[l] (l = 0..n_hidden, shapes as above) and
+ * writes d<gbar_x, g_x>/dg_out into ghat_out [P, n_out].  Nothing reaches x or the biases (the ReLU masks are
+ * locally constant).  Needs 3 KB of scratch per point and hidden layer. */
+int pir_mlp_backward_tangent(const void* packed, size_t mats_floats, const PirMlpPlan* plan, int k0, const float* X,
+                             long P, const float* g_out, const float* gbar_x, float* ghat_out, float* const* gw,
+                             void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ------------------------------------------------ */
 
 /* Kernel families timed by the optional HIP-event profiler. */

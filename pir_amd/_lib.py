@@ -78,6 +78,8 @@ def _declare(L):
     L.pir_mlp_backward_scratch_bytes.argtypes = [i32, lg]
     L.pir_mlp_backward.restype = i32
     L.pir_mlp_backward.argtypes = [vp, sz, vp, i32, vp, lg, vp, vp, ctypes.POINTER(vp), ctypes.POINTER(vp), vp, sz, vp]
+    L.pir_mlp_backward_tangent.restype = i32
+    L.pir_mlp_backward_tangent.argtypes = [vp, sz, vp, i32, vp, lg, vp, vp, vp, ctypes.POINTER(vp), vp, sz, vp]
     L.pir_profile_enable.restype = i32
     L.pir_profile_enable.argtypes = [i32]
     L.pir_profile_read.restype = i32

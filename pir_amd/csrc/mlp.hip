@@ -314,6 +314,79 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
   }
 }
 
+// ---- second-order backward (the smoothness loss differentiates g_x = d out / d x once more) -----------------------
+// With the ReLU masks m_l locally constant, <gbar_x, g_x> = <W_out t_{L-1}, g_out> for the forward-mode tangent
+//   t_0 = m_0 (.) W_0 gbar_x,   t_l = m_l (.) (W_l t_{l-1} [+ W_skip,x gbar_x]),
+// so d/dW_l = dz_l t_{l-1}^T (t_{-1} = gbar_x), d/dW_out = g_out t_{L-1}^T, d/dg_out = W_out t_{L-1}, and nothing
+// reaches x or the biases.  This kernel is the forward kernel on gbar_x without biases, masked by the stored H_l.
+__device__ __forceinline__ void epilogue_mask(Lds& lds, f32x16 (&acc)[kSets][kTPW], const float* __restrict__ Hl,
+                                              float* __restrict__ Tl, long row0) {
+  const int lane = lane_id(), h = lane >> 5, w = wave_id(), j = lane & 31;
+#pragma unroll
+  for (int t = 0; t < kTPW; ++t) {
+    const int T = kTPW * w + t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int s = 0; s < kSets; ++s) {
+        const size_t off = (size_t)(row0 + 32 * s + j) * 256 + 32 * T + 8 * g + 4 * h;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(Hl + off);
+        f32x4 tv;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) tv[c] = a[c] > 0.f ? acc[s][t][4 * g + c] : 0.f;
+        lds.act[s][4 * T + g][lane] = tv;
+        *reinterpret_cast<f32x4*>(Tl + off) = tv;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads, kWavesPerSimd)
+mlp_tangent_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, MlpPlan pl,
+                   const float* __restrict__ GX, long chunk_base, int chunk_n, const float* __restrict__ H,
+                   float* __restrict__ Tn, size_t stride, float* __restrict__ ghat_out) {
+  __shared__ Lds lds;
+  const int lane = lane_id(), w = wave_id();
+  const int ntiles = (chunk_n + kWgPts - 1) / kWgPts;
+  const long chunk_end = chunk_base + chunk_n;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long base = chunk_base + (long)tile * kWgPts;
+    const long row0 = (long)tile * kWgPts;
+    f32x16 acc[kSets][kTPW];
+    zero_acc(acc);
+    input_gemm(lds, mats, pl.prod_in, pl.kin_kb, GX, base, chunk_end, acc);
+    __syncthreads();
+    epilogue_mask(lds, acc, H, Tn, row0);
+    __syncthreads();
+#pragma nounroll
+    for (int l = 1; l < pl.n_hidden; ++l) {
+      zero_acc(acc);
+      gemm_phase<kTPW>(mats, Prod{pl.prod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
+      if (l == pl.skip) input_gemm(lds, mats, pl.prod_skip_x, pl.kin_kb, GX, base, chunk_end, acc);
+      __syncthreads();
+      epilogue_mask(lds, acc, H + (size_t)l * stride, Tn + (size_t)l * stride, row0);
+      __syncthreads();
+    }
+    for (int o = 0; o < pl.n_out; ++o) {
+      float part[kSets];
+      head_partial(lds, vecs + pl.head_off + 256 * o, part);
+      if (lane < 32) { lds.red[w][0][lane][o] = part[0]; lds.red[w][1][lane][o] = part[1]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < kWgPts) {
+      const long Q = base + threadIdx.x;
+      if (Q < chunk_end) {
+        for (int o = 0; o < pl.n_out; ++o) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < kWaves; ++ww) sacc += lds.red[ww][threadIdx.x >> 5][threadIdx.x & 31][o];
+          ghat_out[Q * pl.n_out + o] = sacc;
+        }
+      }
+    }
+  }
+}
+
 // dW_out[o][f] += sum_p g_out[p][o] a_{L-1}[p][f],  db_out[o] += sum_p g_out[p][o]   (n_out <= 4)
 constexpr int kHeadBlocks = 512;
 __global__ void __launch_bounds__(256)
@@ -347,7 +420,7 @@ mlp_head_reduce_kernel(const float* __restrict__ partial, int n_out, float* __re
     if (col == 0) sg += partial[((size_t)b * 4 + o) * 257 + 256];
   }
   gw[o * 256 + col] += s;
-  if (col == 0) gb[o] += sg;
+  if (col == 0 && gb) gb[o] += sg;
 }
 
 static bool plan_ok(const MlpPlan& pl) {
@@ -476,6 +549,91 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
                        g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
     hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
                        out.b[L]);
+    rc = pir_check_launch();
+    if (rc != PIR_OK) return rc;
+  }
+  return PIR_OK;
+}
+
+int pir_mlp_backward_tangent(const void* packed, size_t mats_floats, const PirMlpPlan* plan, int k0, const float* X,
+                             long P, const float* g_out, const float* gbar_x, float* ghat_out, float* const* gw,
+                             void* scratch, size_t scratch_bytes, void* stream_) {
+  if (!packed || !plan || P < 0 || (mats_floats & 3) || !gw) return PIR_ERR_ARG;
+  MlpPlan pl;
+  memcpy(&pl, plan, sizeof(pl));
+  if (!plan_ok(pl) || !pl.has_bwd || pl.n_out > 4 || k0 < 1 || k0 > 8 * pl.kin_kb) return PIR_ERR_ARG;
+  if (P == 0) return PIR_OK;
+  if (!X || !g_out || !gbar_x || !ghat_out || !scratch) return PIR_ERR_ARG;
+  const int L = pl.n_hidden;
+  GradOut out;
+  for (int l = 0; l < 9; ++l) { out.w[l] = l <= L ? gw[l] : nullptr; out.b[l] = nullptr; }
+  for (int l = 0; l <= L; ++l) if (!out.w[l]) return PIR_ERR_ARG;
+  const size_t head_bytes = ((size_t)kHeadBlocks * 4 * 257 * 4 + 255) & ~(size_t)255;
+  const size_t row_bytes = (size_t)L * 3 * 1024;
+  if (scratch_bytes < wgrad_fixed_bytes() + head_bytes + 256 + 64 * row_bytes) return PIR_ERR_SCRATCH;
+  long cap = (long)((scratch_bytes - wgrad_fixed_bytes() - head_bytes - 256) / row_bytes) / 64 * 64;
+  if (cap > 262144) cap = 262144;
+  const WgFixed fx = wgrad_carve(scratch);
+  float* head_partial = (float*)fx.rest;
+  MlpBwdScratch sc;
+  sc.stride = (size_t)cap * 256;
+  sc.H = (float*)(fx.rest + head_bytes);
+  sc.DZ = sc.H + (size_t)L * sc.stride;
+  float* Tn = sc.DZ + (size_t)L * sc.stride;
+  const f32x4* mats = (const f32x4*)packed;
+  const float* vecs = (const float*)packed + mats_floats;
+  const int kpad = 8 * pl.kin_kb;
+  const float is2 = 0.70710678118654752440f;
+  hipStream_t stream = (hipStream_t)stream_;
+  for (long base = 0; base < P; base += cap) {
+    const int n = (int)(P - base < cap ? P - base : cap);
+    const int n_rows = (n + 31) / 32 * 32;
+    const int ntiles = (n + kWgPts - 1) / kWgPts;
+    const long resident = 2L * pir_num_cus();
+    const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
+    {
+      PirProfScope prof(PIR_K_MLP_BWD, (double)n, stream_);
+      hipLaunchKernelGGL(mlp_bwd_sweep_kernel, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, X, g_out, base, n, P,
+                         sc, (float*)nullptr);
+      hipLaunchKernelGGL(mlp_tangent_kernel, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, gbar_x, base, n,
+                         (const float*)sc.H, Tn, sc.stride, ghat_out);
+    }
+    int rc = pir_check_launch();
+    if (rc != PIR_OK) return rc;
+    WgJobs jobs;
+    jobs.n = 0;
+    auto flush = [&]() -> int {
+      if (jobs.n == 0) return PIR_OK;
+      const int r = wgrad_run(jobs, n_rows, n, fx, nullptr, out, PIR_K_MLP_BWD, stream_);
+      jobs.n = 0;
+      return r;
+    };
+    auto add = [&](int l, const float* Y, int ldy, int y_rows, int ncols_y, int dest_cols, int col_off, float scale) -> int {
+      for (int ot = 0; ot < 2; ++ot)
+        for (int i0 = 0; i0 < ncols_y; i0 += 128) {
+          if (jobs.n == kMaxJobs) { const int r = flush(); if (r != PIR_OK) return r; }
+          WgJob& j = jobs.j[jobs.n++];
+          j.X1 = sc.DZ + (size_t)l * sc.stride; j.X2 = nullptr; j.Y1 = Y; j.Y2 = nullptr;
+          j.ldy = ldy; j.x1_rows = -1; j.y1_rows = y_rows;
+          j.o0 = 128 * ot; j.i0 = i0;
+          j.layer = l; j.row_off = 0; j.rows = 256; j.cols = dest_cols; j.col_off = col_off; j.i_limit = ncols_y;
+          j.scale = scale; j.bias = 0;
+        }
+      return PIR_OK;
+    };
+    const float* Gc = gbar_x + (size_t)base * kpad;
+    rc = add(0, Gc, kpad, n, k0, k0, 0, 1.0f);
+    for (int l = 1; l < L && rc == PIR_OK; ++l) {
+      const bool sk = l == pl.skip;
+      rc = add(l, Tn + (size_t)(l - 1) * sc.stride, 256, -1, 256, sk ? 256 + k0 : 256, 0, sk ? is2 : 1.0f);
+      if (rc == PIR_OK && sk) rc = add(l, Gc, kpad, n, k0, 256 + k0, 256, is2);
+    }
+    if (rc == PIR_OK) rc = flush();
+    if (rc != PIR_OK) return rc;
+    hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(kHeadBlocks), dim3(256), 0, stream, Tn + (size_t)(L - 1) * sc.stride,
+                       g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
+    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
+                       (float*)nullptr);
     rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
   }

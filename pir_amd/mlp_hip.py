@@ -170,8 +170,7 @@ def packed_for(mod) -> PackedMlp:
 
 
 def mlp_apply_eager(mod, inp):
-    """The eager PyTorch expression (rocBLAS GEMMs): the definition of the result, used for double-backward
-    (the smoothness loss differentiates d material / d points once more, render_surface.py:40-48,76-78)."""
+    """The eager PyTorch expression (rocBLAS GEMMs): the definition of the result."""
     import numpy as np
     import torch.nn.functional as F
     x = inp
@@ -190,8 +189,8 @@ _force_eager = 0
 
 
 class eager_grad:
-    """Context manager: differentiable evaluations inside use the eager expression (needed when the caller will
-    differentiate the result twice; the fused backward is once-differentiable)."""
+    """Context manager: differentiable evaluations inside use the eager PyTorch expression (A/B tests; callers that
+    need derivatives the fused path does not provide, i.e. gradients of parameter gradients)."""
 
     def __enter__(self):
         global _force_eager
@@ -220,42 +219,89 @@ def _backward_scratch(device, n_hidden):
     return buf
 
 
+def _run_backward(packed, xp, g_out, need_gx, shapes):
+    P = xp.shape[0]
+    dev = xp.device
+    nl = packed.n_hidden + 1
+    gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes[:nl]]
+    gbs = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes[nl:]]
+    gx = torch.empty(P, xp.shape[1], dtype=torch.float32, device=dev) if need_gx else None
+    g = g_out.detach().reshape(P, packed.n_out).contiguous().float()
+    scratch = _backward_scratch(dev, packed.n_hidden)
+    wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
+    bp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gbs])
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().pir_mlp_backward(
+            _lib.ptr(packed.buf), packed.mats_floats, ctypes.byref(packed.plan), packed.k0, _lib.ptr(xp), P,
+            _lib.ptr(g), _lib.ptr(gx), wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()),
+            "pir_mlp_backward")
+    return gx, gws, gbs
+
+
 class _MlpFn(torch.autograd.Function):
     """out = fused MLP(inp) on the packed effective weights; backward = pir_mlp_backward (recompute + sweeps +
-    split-K weight-gradient GEMM).  PyTorch chains dW_l -> (weight_g, weight_v) through torch._weight_norm."""
+    split-K weight-gradient GEMM).  PyTorch chains dW_l -> (weight_g, weight_v) through torch._weight_norm.
+    Under create_graph=True the backward is itself recorded (`_MlpBwdFn`), so the input gradient can be
+    differentiated once more (the smoothness loss, render_surface.py:40-48)."""
 
     @staticmethod
     def forward(ctx, mod, inp, *wb):
         packed = packed_for(mod)
-        x2 = inp.reshape(-1, inp.shape[-1])
-        xp = packed.pad_input(x2)
+        xp = packed.pad_input(inp.reshape(-1, inp.shape[-1]))
         out = packed.forward_padded(xp)
         ctx.packed, ctx.xp, ctx.in_shape = packed, xp, inp.shape
         ctx.need_gx = inp.requires_grad
-        ctx.shapes = [tuple(t.shape) for t in wb]
+        ctx.save_for_backward(*wb)
         return out.reshape(*inp.shape[:-1], out.shape[-1])
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, g_out):
+        wb = ctx.saved_tensors
         packed, xp = ctx.packed, ctx.xp
-        P = xp.shape[0]
-        dev = xp.device
-        nl = packed.n_hidden + 1
-        gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes[:nl]]
-        gbs = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes[nl:]]
-        gx = torch.empty(P, xp.shape[1], dtype=torch.float32, device=dev) if ctx.need_gx else None
-        g = g_out.detach().reshape(P, packed.n_out).contiguous().float()
-        scratch = _backward_scratch(dev, packed.n_hidden)
-        wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
-        bp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gbs])
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().pir_mlp_backward(
-                _lib.ptr(packed.buf), packed.mats_floats, ctypes.byref(packed.plan), packed.k0, _lib.ptr(xp), P,
-                _lib.ptr(g), _lib.ptr(gx), wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()),
-                "pir_mlp_backward")
+        if torch.is_grad_enabled() and ctx.need_gx:      # create_graph=True: keep the backward differentiable
+            res = _MlpBwdFn.apply(packed, xp, ctx.in_shape, g_out, *wb)
+            return (None, res[0], *res[1:])
+        gx, gws, gbs = _run_backward(packed, xp, g_out, ctx.need_gx, [tuple(t.shape) for t in wb])
         g_in = gx[:, :packed.k0].reshape(ctx.in_shape) if ctx.need_gx else None
         return (None, g_in, *gws, *gbs)
+
+
+class _MlpBwdFn(torch.autograd.Function):
+    """(g_out, W, b) -> (g_in, gW, gb) of the fused MLP as a differentiable node.  Its backward handles an upstream
+    gradient on g_in (pir_mlp_backward_tangent); upstream gradients on gW / gb are not supported (the reference
+    never differentiates parameter gradients)."""
+
+    @staticmethod
+    def forward(ctx, packed, xp, in_shape, g_out, *wb):
+        gx, gws, gbs = _run_backward(packed, xp, g_out, True, [tuple(t.shape) for t in wb])
+        ctx.packed, ctx.xp, ctx.in_shape = packed, xp, in_shape
+        ctx.g_out = g_out.detach().reshape(xp.shape[0], packed.n_out).contiguous().float()
+        ctx.g_out_shape = g_out.shape
+        ctx.shapes = [tuple(t.shape) for t in wb]
+        ctx.set_materialize_grads(False)
+        return (gx[:, :packed.k0].reshape(in_shape), *gws, *gbs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gbar_in, *gbar_wb):
+        if any(g is not None for g in gbar_wb):
+            raise NotImplementedError("pir_amd: gradients of the material networks' parameter gradients are not supported")
+        nl = ctx.packed.n_hidden + 1
+        if gbar_in is None:
+            return (None,) * (4 + 2 * nl)
+        packed, xp = ctx.packed, ctx.xp
+        P, dev = xp.shape[0], xp.device
+        gbar = packed.pad_input(gbar_in.reshape(P, packed.k0))
+        ghat = torch.empty(P, packed.n_out, dtype=torch.float32, device=dev)
+        gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes[:nl]]
+        scratch = _backward_scratch(dev, packed.n_hidden)
+        wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().pir_mlp_backward_tangent(
+                _lib.ptr(packed.buf), packed.mats_floats, ctypes.byref(packed.plan), packed.k0, _lib.ptr(xp), P,
+                _lib.ptr(ctx.g_out), _lib.ptr(gbar), _lib.ptr(ghat), wp, _lib.ptr(scratch), scratch.numel(),
+                _lib.stream_ptr()), "pir_mlp_backward_tangent")
+        return (None, None, None, ghat.reshape(ctx.g_out_shape), *gws, *([None] * nl))
 
 
 def mlp_apply_fused(mod, inp):

@@ -247,10 +247,8 @@ class RenderingNetwork(nn.Module):
 
     @torch.enable_grad()
     def get_all(self, points, normals, view_dirs, geo_f, semantic_f=None, is_training=True):
-        from . import mlp_hip
         semantic_f.requires_grad_(True)
-        with mlp_hip.eager_grad():   # differentiated again by the caller when is_training
-            y = self.forward(points, normals, view_dirs, geo_f, semantic_f)
+        y = self.forward(points, normals, view_dirs, geo_f, semantic_f)
         (g,) = torch.autograd.grad(y, semantic_f, torch.ones_like(y), create_graph=is_training, retain_graph=is_training)
         return (y, g) if is_training else (y.detach(), g.detach())
 

@@ -4,11 +4,7 @@ The reference defines render_fn / get_materials at module level with globals (ar
 args.smoothness_weight, ggx_renderer_modified, dino_dimension); `make_render_fn` binds those explicitly and
 returns a callable with the reference's signature and result dictionary.
 """
-import contextlib
-
 import torch
-
-from . import mlp_hip
 
 dino_dimension = 384
 
@@ -24,17 +20,14 @@ def make_render_fn(ggx_renderer, is_metal=False, smoothness_weight=0.0):
         nets = color_network_dict
         smooth = smoothness_weight > 0 and is_training and not roughness_warmup
         kd = nets["diffuse_albedo_network"](points, normals, -normals, geo_f, None).abs()[..., [2, 1, 0]]
-        # the smoothness loss differentiates d ks / d points and d roughness / d points once more: those two
-        # evaluations then use the twice-differentiable eager expression instead of the fused kernels
-        with (mlp_hip.eager_grad() if smooth else contextlib.nullcontext()):
-            ks = nets["specular_albedo_network"](points, normals, None, geo_f, dino_f).abs()
-            if not is_metal:
-                ks = ks.mean(dim=-1, keepdim=True).expand_as(ks)
-            if roughness_warmup:
-                rough = torch.full((ks.shape[0], 1), 0.10, device=points.device)
-            else:
-                rough = nets["specular_roughness_network"](points, normals, None, geo_f, dino_f).abs() + 0.01
-        if smooth:
+        ks = nets["specular_albedo_network"](points, normals, None, geo_f, dino_f).abs()
+        if not is_metal:
+            ks = ks.mean(dim=-1, keepdim=True).expand_as(ks)
+        if roughness_warmup:
+            rough = torch.full((ks.shape[0], 1), 0.10, device=points.device)
+        else:
+            rough = nets["specular_roughness_network"](points, normals, None, geo_f, dino_f).abs() + 0.01
+        if smooth:   # differentiates the material outputs w.r.t. the points once more (fused: pir_mlp_backward_tangent)
             ks_g, rough_g = get_material_grads(ks, points), get_material_grads(rough, points)
         else:
             ks_g, rough_g = torch.zeros_like(ks), torch.zeros_like(rough[..., 0:1])
