@@ -225,3 +225,41 @@ def test_fused_material_networks_match_reference_fixture():
             ref = d[f"{name}.g.{k}"]
             g = p.grad.cpu().numpy()
             assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 2e-4, (name, k)
+
+
+def test_mlp_entry_points_reject_bad_arguments():
+    """C-ABI error behaviour: malformed plans, missing pointers, scratch too small; P = 0 is accepted and does nothing."""
+    import ctypes
+    from pir_amd import scene, mlp_hip, _lib
+    _, mats, dinonet = scene.build_networks(seed=1, device="cuda")
+    pk = mlp_hip.packed_for(mats["specular_roughness_network"])
+    L = _lib.lib()
+    x = torch.zeros(64, 8 * pk.kin_kb, device="cuda")
+    out = torch.zeros(64, pk.n_out, device="cuda")
+    st = _lib.stream_ptr()
+    ok = L.pir_mlp_forward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(pk.plan), _lib.ptr(x), 0, None, st)
+    assert ok == 0                                                      # empty input
+    assert L.pir_mlp_forward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(pk.plan), None, 64, _lib.ptr(out), st) == 1
+    bad = mlp_hip.PirMlpPlan.from_buffer_copy(pk.plan)
+    bad.n_hidden = 9
+    assert L.pir_mlp_forward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(bad), _lib.ptr(x), 64, _lib.ptr(out), st) == 1
+    bad = mlp_hip.PirMlpPlan.from_buffer_copy(pk.plan)
+    bad.skip = 0
+    assert L.pir_mlp_forward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(bad), _lib.ptr(x), 64, _lib.ptr(out), st) == 1
+    nl = pk.n_hidden + 1
+    gws = [torch.zeros(256, 8, device="cuda") for _ in range(nl)]
+    wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
+    small = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = L.pir_mlp_backward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(pk.plan), pk.k0, _lib.ptr(x), 64, _lib.ptr(out),
+                            None, wp, wp, _lib.ptr(small), small.numel(), st)
+    assert rc == 3                                                      # scratch too small
+    # the DINO field is packed for inference only (no transposed products): its backward is refused
+    pd = mlp_hip.packed_for(dinonet)
+    assert pd.plan.has_bwd == 0
+    big = mlp_hip._backward_scratch(torch.device("cuda", 0), pd.n_hidden)
+    xd = torch.zeros(64, 8 * pd.kin_kb, device="cuda")
+    gd = torch.zeros(64, pd.n_out, device="cuda")
+    rc = L.pir_mlp_backward(_lib.ptr(pd.buf), pd.mats_floats, ctypes.byref(pd.plan), pd.k0, _lib.ptr(xd), 64, _lib.ptr(gd),
+                            None, wp, wp, _lib.ptr(big), big.numel(), st)
+    assert rc == 1
+    torch.cuda.synchronize()
