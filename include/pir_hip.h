@@ -154,6 +154,7 @@ typedef struct PirMlpPlan {
   int rprod_h[8];    /* W_l^T, l = 1..n_hidden-1: 32 k-blocks each */
   int rprod_in;      /* W_0^T: ceil(kin_kb / 32) passes of 256 input columns x 32 k-blocks */
   int rprod_skip_x;  /* the x part of the skip layer, transposed: same shape */
+  int rprod_out;     /* W_out^T over the outputs: n_out / 8 k-blocks (n_out > 4, a multiple of 8, only) */
 } PirMlpPlan;
 
 /* out [P, n_out] = last layer(relu(...relu(lin0 x)...)) for x [P, 8 kin_kb] (zero-padded input rows).
@@ -166,7 +167,8 @@ int pir_mlp_forward(const void* packed, size_t mats_floats, const PirMlpPlan* pl
  * activations and pre-activation gradients, 2 KB per point and hidden layer). */
 size_t pir_mlp_backward_scratch_bytes(int n_hidden, long chunk_points);
 
-/* Backward of pir_mlp_forward (what autograd derives for src/network.py:232-243; n_out <= 4): given g_out [P, n_out]
+/* Backward of pir_mlp_forward (what autograd derives for src/network.py:232-243; n_out <= 4 or a multiple of 8):
+ * given g_out [P, n_out]
  * accumulates (+=) dL/dW_l into gw[l] (row-major, the true shapes [256, k0], [256, 256], [256, 256 + k0] for the
  * skip layer, [n_out, 256]) and dL/db_l into gb[l], l = 0..n_hidden, and writes dL/dx into g_x [P, 8 kin_kb] if
  * non-NULL.  gw / gb: HOST arrays of n_hidden + 1 device pointers, zero-initialised by the caller.  k0 = true input

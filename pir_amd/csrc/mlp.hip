@@ -44,6 +44,7 @@ struct MlpPlan {
   int rprod_h[8];    //   W_l^T over the 256 outputs of hidden layer l (32 k-blocks), l = 1..n_hidden-1
   int rprod_in;      //   W_0^T: ceil(kin_kb / 32) passes of 256 input columns, 32 k-blocks each
   int rprod_skip_x;  //   the x part of the skip layer, transposed: same shape as rprod_in
+  int rprod_out;     //   W_out^T over the n_out outputs (n_out / 8 k-blocks; n_out > 4 only, n_out % 8 == 0)
 };
 
 // x-slice of both operand sets -> activation region, then acc += W[:, slice] x slice, for every slice of the input.
@@ -232,6 +233,33 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
     const long base = chunk_base + (long)tile * kWgPts;
     const long row0 = (long)tile * kWgPts;
     mlp_hidden<true>(lds, mats, vecs, pl, X, base, chunk_end, sc.H, sc.stride, row0, rpad);
+    f32x16 acc[kSets][kTPW];
+    if (pl.n_out > 4) {
+      // ---- wide output layer (DINO field): dz_{L-1} = (W_out^T g_out) (.) [a_{L-1} > 0] on MFMA, g_out rows streamed
+      // through the activation region like an input (the mask comes from the stored H_{L-1})
+      zero_acc(acc);
+      input_gemm(lds, mats, pl.rprod_out, pl.n_out / 8, g_out, base, chunk_end, acc);
+      __syncthreads();
+      const float* Hl = sc.H + (size_t)(L - 1) * sc.stride;
+      float* DZl = sc.DZ + (size_t)(L - 1) * sc.stride;
+#pragma unroll
+      for (int t = 0; t < kTPW; ++t) {
+        const int T = kTPW * w + t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+          for (int s = 0; s < kSets; ++s) {
+            const size_t off = (size_t)(row0 + 32 * s + j) * 256 + 32 * T + 8 * g + 4 * h;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(Hl + off);
+            f32x4 dz;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dz[c] = a[c] > 0.f ? acc[s][t][4 * g + c] : 0.f;
+            lds.act[s][4 * T + g][lane] = dz;
+            *reinterpret_cast<f32x4*>(DZl + off) = dz;
+          }
+        }
+      }
+    } else {
     // ---- output layer: dz_{L-1} from g_out, masked by the activations still in LDS
     float go[kSets][4];
 #pragma unroll
@@ -266,9 +294,9 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
         }
       }
     }
+    }
     __syncthreads();
     // ---- hidden layers, last to first
-    f32x16 acc[kSets][kTPW];
 #pragma nounroll
     for (int l = L - 1; l >= 1; --l) {
       if (l == pl.skip && g_x) {   // the x share of the skip layer's input gradient
@@ -478,7 +506,7 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
   if (!packed || !plan || P < 0 || (mats_floats & 3) || !gw || !gb) return PIR_ERR_ARG;
   MlpPlan pl;
   memcpy(&pl, plan, sizeof(pl));
-  if (!plan_ok(pl) || !pl.has_bwd || pl.n_out > 4 || k0 < 1 || k0 > 8 * pl.kin_kb) return PIR_ERR_ARG;
+  if (!plan_ok(pl) || !pl.has_bwd || (pl.n_out > 4 && (pl.n_out & 7)) || k0 < 1 || k0 > 8 * pl.kin_kb) return PIR_ERR_ARG;
   if (P == 0) return PIR_OK;
   if (!X || !g_out || !scratch) return PIR_ERR_ARG;
   const int L = pl.n_hidden;
@@ -529,7 +557,7 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
           if (jobs.n == kMaxJobs) { const int r = flush(); if (r != PIR_OK) return r; }
           WgJob& j = jobs.j[jobs.n++];
           j.X1 = sc.DZ + (size_t)l * sc.stride; j.X2 = nullptr; j.Y1 = Y; j.Y2 = nullptr;
-          j.ldy = ldy; j.x1_rows = -1; j.y1_rows = y_rows;
+          j.ldx = 256; j.ldy = ldy; j.x1_rows = -1; j.y1_rows = y_rows;
           j.o0 = 128 * ot; j.i0 = i0;
           j.layer = l; j.row_off = 0; j.rows = 256; j.cols = dest_cols; j.col_off = col_off; j.i_limit = ncols_y;
           j.scale = scale; j.bias = with_bias && i0 == 0;
@@ -543,14 +571,29 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
       rc = add(l, sc.H + (size_t)(l - 1) * sc.stride, 256, -1, 256, sk ? 256 + k0 : 256, 0, sk ? is2 : 1.0f, true);
       if (rc == PIR_OK && sk) rc = add(l, Xc, kpad, n, k0, 256 + k0, 256, is2, false);
     }
+    if (rc == PIR_OK && pl.n_out > 4) {
+      // wide output layer: dW_out = g_out^T H_{L-1} ([n_out, 256]) and db_out through the same GEMM, g_out as the X operand
+      for (int o0 = 0; o0 < pl.n_out && rc == PIR_OK; o0 += 128)
+        for (int i0 = 0; i0 < 256; i0 += 128) {
+          if (jobs.n == kMaxJobs) { rc = flush(); if (rc != PIR_OK) break; }
+          WgJob& j = jobs.j[jobs.n++];
+          j.X1 = g_out + (size_t)base * pl.n_out; j.X2 = nullptr; j.Y1 = sc.H + (size_t)(L - 1) * sc.stride; j.Y2 = nullptr;
+          j.ldx = pl.n_out; j.ldy = 256; j.x1_rows = n; j.y1_rows = -1;
+          j.o0 = o0; j.i0 = i0;
+          j.layer = L; j.row_off = 0; j.rows = pl.n_out; j.cols = 256; j.col_off = 0; j.i_limit = 256;
+          j.scale = 1.0f; j.bias = i0 == 0;
+        }
+    }
     if (rc == PIR_OK) rc = flush();
     if (rc != PIR_OK) return rc;
-    hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(kHeadBlocks), dim3(256), 0, stream, sc.H + (size_t)(L - 1) * sc.stride,
-                       g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
-    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
-                       out.b[L]);
-    rc = pir_check_launch();
-    if (rc != PIR_OK) return rc;
+    if (pl.n_out <= 4) {
+      hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(kHeadBlocks), dim3(256), 0, stream, sc.H + (size_t)(L - 1) * sc.stride,
+                         g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
+      hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
+                         out.b[L]);
+      rc = pir_check_launch();
+      if (rc != PIR_OK) return rc;
+    }
   }
   return PIR_OK;
 }
@@ -614,7 +657,7 @@ int pir_mlp_backward_tangent(const void* packed, size_t mats_floats, const PirMl
           if (jobs.n == kMaxJobs) { const int r = flush(); if (r != PIR_OK) return r; }
           WgJob& j = jobs.j[jobs.n++];
           j.X1 = sc.DZ + (size_t)l * sc.stride; j.X2 = nullptr; j.Y1 = Y; j.Y2 = nullptr;
-          j.ldy = ldy; j.x1_rows = -1; j.y1_rows = y_rows;
+          j.ldx = 256; j.ldy = ldy; j.x1_rows = -1; j.y1_rows = y_rows;
           j.o0 = 128 * ot; j.i0 = i0;
           j.layer = l; j.row_off = 0; j.rows = 256; j.cols = dest_cols; j.col_off = col_off; j.i_limit = ncols_y;
           j.scale = scale; j.bias = 0;

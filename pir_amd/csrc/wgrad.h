@@ -10,6 +10,7 @@ constexpr int kKSplitMax = 64;
 struct WgJob {
   const float* X1; const float* Y1;   // product 1 (Zb, H): C += X1^T Y1 over the rows (points) of a chunk
   const float* X2; const float* Y2;   // product 2 (Q, Pb) or null
+  int ldx;                            // leading dimension of X (256; n_out for a caller-owned wide g_out)
   int ldy;                            // leading dimension of Y (256; 64 for the SDF encoding arrays; the padded
                                       // input width of a material network)
   int x1_rows;                        // rows of X1 that exist (caller-owned g_feat is not padded); <0: all

@@ -65,7 +65,7 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __
   TileRegs tx, ty;
   auto fetch = [&](int step) {
     const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts;
-    load_tile(tx, prod ? jb.X2 : jb.X1, 256, jb.o0, row0, prod ? -1 : jb.x1_rows);
+    load_tile(tx, prod ? jb.X2 : jb.X1, prod ? 256 : jb.ldx, jb.o0, row0, prod ? -1 : jb.x1_rows);
     load_tile(ty, prod ? jb.Y2 : jb.Y1, jb.ldy, jb.i0, row0, prod ? -1 : jb.y1_rows);
   };
   if (nsteps > 0) fetch(0);
@@ -278,7 +278,7 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
           j.X1 = sc.Zb(l); j.X2 = sc.Q(l);
           j.Y1 = l == 0 ? sc.E : sc.A(l - 1);
           j.Y2 = l == 0 ? sc.Ed : sc.Ad(l - 1);
-          j.ldy = l == 0 ? 64 : 256;
+          j.ldx = 256; j.ldy = l == 0 ? 64 : 256;
           j.x1_rows = -1; j.y1_rows = -1;
           j.o0 = 128 * ot; j.i0 = 128 * itl;
           j.layer = l; j.row_off = 0; j.rows = rows[l]; j.cols = cols[l]; j.col_off = 0; j.i_limit = cols[l];
@@ -291,7 +291,7 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
         for (int itl = 0; itl < 2; ++itl) {
           WgJob& j = jobs.j[jobs.n++];
           j.X1 = g_feat + (size_t)base * 256; j.X2 = nullptr; j.Y1 = sc.A(7); j.Y2 = nullptr;
-          j.ldy = 256; j.x1_rows = n; j.y1_rows = -1; j.o0 = 128 * ot; j.i0 = 128 * itl;
+          j.ldx = 256; j.ldy = 256; j.x1_rows = n; j.y1_rows = -1; j.o0 = 128 * ot; j.i0 = 128 * itl;
           j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.col_off = 0; j.i_limit = 256; j.scale = 1.0f; j.bias = itl == 0;
         }
     }

@@ -22,7 +22,7 @@ class PirMlpPlan(ctypes.Structure):
                 ("prod_in", ctypes.c_int), ("prod_h", ctypes.c_int * 8), ("prod_skip_x", ctypes.c_int),
                 ("prod_out", ctypes.c_int), ("bias_off", ctypes.c_int), ("head_off", ctypes.c_int),
                 ("out_bias_off", ctypes.c_int), ("has_bwd", ctypes.c_int), ("rprod_h", ctypes.c_int * 8),
-                ("rprod_in", ctypes.c_int), ("rprod_skip_x", ctypes.c_int)]
+                ("rprod_in", ctypes.c_int), ("rprod_skip_x", ctypes.c_int), ("rprod_out", ctypes.c_int)]
 
 
 def supported_shapes(shapes, skip: Optional[int]) -> bool:
@@ -84,9 +84,8 @@ class PackedMlp:
             plan.prod_out = off // 4
             for p in range(passes):
                 add(ws[-1], 256 * p, min(256, self.n_out - 256 * p), 0, _HIDDEN, 0, 1.0, _ACT_KB)
-        # transposed products of the backward (networks with a VALU head only: the DINO field is never trained
-        # through this path, render_surface.py:549,686-699)
-        plan.has_bwd = 1 if self.n_out <= 4 else 0
+        # transposed products of the backward
+        plan.has_bwd = 1 if (self.n_out <= 4 or self.n_out % 8 == 0) else 0
         if plan.has_bwd:
             xpasses = (self.kin_kb + _ACT_KB - 1) // _ACT_KB
             for l in range(1, self.n_hidden):
@@ -98,6 +97,8 @@ class PackedMlp:
                 plan.rprod_skip_x = off // 4
                 for p in range(xpasses):
                     add(ws[skip], 0, min(256, self.k0 - 256 * p), _HIDDEN + 256 * p, _HIDDEN, 1, is2, _ACT_KB)
+            if self.n_out > 4:
+                plan.rprod_out = add(ws[-1], 0, _HIDDEN, 0, self.n_out, 1, 1.0, self.n_out // 8)
         self.mats_floats = off
         # ---- vectors
         voff = 0
@@ -258,7 +259,7 @@ class _MlpFn(torch.autograd.Function):
     def backward(ctx, g_out):
         wb = ctx.saved_tensors
         packed, xp = ctx.packed, ctx.xp
-        if torch.is_grad_enabled() and ctx.need_gx:      # create_graph=True: keep the backward differentiable
+        if torch.is_grad_enabled() and ctx.need_gx and packed.n_out <= 4:   # create_graph=True: keep it differentiable
             res = _MlpBwdFn.apply(packed, xp, ctx.in_shape, g_out, *wb)
             return (None, res[0], *res[1:])
         gx, gws, gbs = _run_backward(packed, xp, g_out, ctx.need_gx, [tuple(t.shape) for t in wb])

@@ -253,13 +253,39 @@ def test_mlp_entry_points_reject_bad_arguments():
     rc = L.pir_mlp_backward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(pk.plan), pk.k0, _lib.ptr(x), 64, _lib.ptr(out),
                             None, wp, wp, _lib.ptr(small), small.numel(), st)
     assert rc == 3                                                      # scratch too small
-    # the DINO field is packed for inference only (no transposed products): its backward is refused
-    pd = mlp_hip.packed_for(dinonet)
-    assert pd.plan.has_bwd == 0
-    big = mlp_hip._backward_scratch(torch.device("cuda", 0), pd.n_hidden)
-    xd = torch.zeros(64, 8 * pd.kin_kb, device="cuda")
-    gd = torch.zeros(64, pd.n_out, device="cuda")
-    rc = L.pir_mlp_backward(_lib.ptr(pd.buf), pd.mats_floats, ctypes.byref(pd.plan), pd.k0, _lib.ptr(xd), 64, _lib.ptr(gd),
+    # a plan without transposed products (packed for inference only) is refused by the backward
+    big = mlp_hip._backward_scratch(torch.device("cuda", 0), pk.n_hidden)
+    bad = mlp_hip.PirMlpPlan.from_buffer_copy(pk.plan)
+    bad.has_bwd = 0
+    rc = L.pir_mlp_backward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(bad), pk.k0, _lib.ptr(x), 64, _lib.ptr(out),
                             None, wp, wp, _lib.ptr(big), big.numel(), st)
     assert rc == 1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("P", [65, 20000])
+def test_dino_field_backward_matches_eager(P):
+    """DINONetwork(is_training=True) as train_dino uses it (render_surface.py:435-492): 384 outputs through the
+    tile-pass output layer, backward through the transposed output product and the shared weight-gradient GEMM."""
+    from pir_amd import scene, mlp_hip
+    _, _, dinonet = scene.build_networks(seed=6, device="cuda")
+    pts = (torch.rand(P, 3, generator=torch.Generator().manual_seed(P)) - 0.5).cuda()
+    w = torch.randn(P, 384, generator=torch.Generator().manual_seed(1)).cuda()
+    res = []
+    for mode in ("fused", "eager"):
+        p = pts.clone().requires_grad_(True)
+        dinonet.zero_grad()
+        if mode == "eager":
+            with mlp_hip.eager_grad():
+                out = dinonet(p, is_training=True)
+        else:
+            out = dinonet(p, is_training=True)
+            assert _graph_has(out.grad_fn, "_MlpFn")
+        (out * w).sum().backward()
+        res.append((out.detach(), p.grad.clone(), {k: q.grad.clone() for k, q in dinonet.named_parameters()}))
+    (o0, p0, g0), (o1, p1, g1) = res
+    assert rel_err(o0.cpu().numpy(), o1.cpu().numpy()) < 2e-5
+    row = (p0 - p1).abs().max(-1).values / p1.abs().max()
+    assert (row > 1e-4).float().mean().item() < 2e-3
+    errs = [rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) for k in g0]
+    assert float(np.median(errs)) < 5e-4 and max(errs) < 1e-2, errs
