@@ -26,21 +26,50 @@ class PirMlpPlan(ctypes.Structure):
 
 
 def supported_shapes(shapes, skip: Optional[int]) -> bool:
-    """shapes: [(out, in)] of lin0..lin_last.  Hidden layers 256 wide, at most 8 of them, one optional skip layer."""
+    """shapes: [(out, in)] of lin0..lin_last.  Hidden layers of one width <= 256 (narrower ones run zero-padded to
+    256: relu(0) = 0, so the result is unchanged), at most 8 of them, one optional skip layer."""
     n_hidden = len(shapes) - 1
     if not 1 <= n_hidden <= 8:
         return False
-    k0 = shapes[0][1]
+    k0, hid = shapes[0][1], shapes[0][0]
+    if not 1 <= hid <= _HIDDEN:
+        return False
     for l, (o, i) in enumerate(shapes[:-1]):
-        if o != _HIDDEN:
+        if o != hid:
             return False
-        want_in = k0 if l == 0 else (_HIDDEN + k0 if l == skip else _HIDDEN)
+        want_in = k0 if l == 0 else (hid + k0 if l == skip else hid)
         if i != want_in:
             return False
     n_out, last_in = shapes[-1]
-    if last_in != _HIDDEN or n_out < 1 or (n_out > 4 and n_out % 4):
+    if last_in != hid or n_out < 1 or (n_out > 4 and n_out % 4):
         return False
     return skip is None or 1 <= skip < n_hidden
+
+
+def _pad_to_engine_width(ws, bs, skip):
+    """Zero-pad hidden layers narrower than 256 to the engine's width (rows of every hidden layer, the matching
+    input columns of the next one)."""
+    hid = ws[0].shape[0]
+    if hid == _HIDDEN:
+        return ws, bs
+    k0 = ws[0].shape[1]
+    out_w, out_b = [], []
+    for l, (w, b) in enumerate(zip(ws, bs)):
+        last = l == len(ws) - 1
+        rows = w.shape[0] if last else _HIDDEN
+        if l == 0:
+            wp = w.new_zeros(rows, k0)
+            wp[:w.shape[0]] = w
+        else:
+            cols = _HIDDEN + (k0 if l == skip else 0)
+            wp = w.new_zeros(rows, cols)
+            wp[:w.shape[0], :hid] = w[:, :hid]
+            if l == skip:
+                wp[:w.shape[0], _HIDDEN:] = w[:, hid:]
+        bp = b if last else torch.cat([b, b.new_zeros(_HIDDEN - hid)])
+        out_w.append(wp.contiguous())
+        out_b.append(bp.contiguous())
+    return out_w, out_b
 
 
 class PackedMlp:
@@ -52,6 +81,8 @@ class PackedMlp:
         assert dev.type == "cuda"
         ws = [w.detach().contiguous().float() for w in weights]
         bs = [b.detach().contiguous().float() for b in biases]
+        self.true_hidden = shapes[0][0]
+        ws, bs = _pad_to_engine_width(ws, bs, skip)
         self.device = dev
         self.k0 = shapes[0][1]
         self.kin_kb = (self.k0 + 7) // 8
@@ -123,6 +154,40 @@ class PackedMlp:
                 _lib.check(L.pir_mlp_pack_product(_lib.ptr(W), ld, row0, nrows, col0, ncols, tr, sc, dst, nkb,
                                                   _lib.stream_ptr()), "pir_mlp_pack_product")
         self._keep = ws   # the pack kernels read them asynchronously
+
+    def padded_shapes(self, shapes):
+        """Shapes of the gradient buffers the kernels write, for the parameter shapes `shapes` = the n_hidden + 1
+        weights followed by the n_hidden + 1 biases."""
+        nl, hid = self.n_hidden + 1, self.true_hidden
+        if hid == _HIDDEN:
+            return [tuple(s) for s in shapes]
+        out = []
+        for idx, s in enumerate(shapes):
+            s = tuple(s)
+            l = idx if idx < nl else idx - nl
+            last = l == nl - 1
+            if idx < nl:
+                out.append((s[0] if last else _HIDDEN, s[1] if l == 0 else _HIDDEN + (s[1] - hid)))
+            else:
+                out.append(s if last else (_HIDDEN,))
+        return out
+
+    def unpad_grads(self, grads, shapes):
+        hid = self.true_hidden
+        if hid == _HIDDEN:
+            return grads
+        out = []
+        for g, s in zip(grads, shapes):
+            s = tuple(s)
+            if g.shape == s:
+                out.append(g)
+            elif g.dim() == 1:
+                out.append(g[:s[0]].contiguous())
+            elif g.shape[1] == s[1]:
+                out.append(g[:s[0]].contiguous())
+            else:   # [256, 256 (+ k0)] -> [hid, hid (+ k0)]
+                out.append(torch.cat([g[:s[0], :hid], g[:s[0], _HIDDEN:]], dim=1).contiguous())
+        return out
 
     def pad_input(self, x: torch.Tensor) -> torch.Tensor:
         """[P, k0] -> contiguous [P, 8 kin_kb] with zero columns appended."""
@@ -224,8 +289,9 @@ def _run_backward(packed, xp, g_out, need_gx, shapes):
     P = xp.shape[0]
     dev = xp.device
     nl = packed.n_hidden + 1
-    gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes[:nl]]
-    gbs = [torch.zeros(s, dtype=torch.float32, device=dev) for s in shapes[nl:]]
+    pshapes = packed.padded_shapes(shapes)
+    gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in pshapes[:nl]]
+    gbs = [torch.zeros(s, dtype=torch.float32, device=dev) for s in pshapes[nl:]]
     gx = torch.empty(P, xp.shape[1], dtype=torch.float32, device=dev) if need_gx else None
     g = g_out.detach().reshape(P, packed.n_out).contiguous().float()
     scratch = _backward_scratch(dev, packed.n_hidden)
@@ -236,6 +302,7 @@ def _run_backward(packed, xp, g_out, need_gx, shapes):
             _lib.ptr(packed.buf), packed.mats_floats, ctypes.byref(packed.plan), packed.k0, _lib.ptr(xp), P,
             _lib.ptr(g), _lib.ptr(gx), wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()),
             "pir_mlp_backward")
+    gws, gbs = packed.unpad_grads(gws, shapes[:nl]), packed.unpad_grads(gbs, shapes[nl:])
     return gx, gws, gbs
 
 
@@ -294,7 +361,7 @@ class _MlpBwdFn(torch.autograd.Function):
         P, dev = xp.shape[0], xp.device
         gbar = packed.pad_input(gbar_in.reshape(P, packed.k0))
         ghat = torch.empty(P, packed.n_out, dtype=torch.float32, device=dev)
-        gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in ctx.shapes[:nl]]
+        gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in packed.padded_shapes(ctx.shapes)[:nl]]
         scratch = _backward_scratch(dev, packed.n_hidden)
         wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
         with torch.cuda.device(dev):
@@ -302,6 +369,7 @@ class _MlpBwdFn(torch.autograd.Function):
                 _lib.ptr(packed.buf), packed.mats_floats, ctypes.byref(packed.plan), packed.k0, _lib.ptr(xp), P,
                 _lib.ptr(ctx.g_out), _lib.ptr(gbar), _lib.ptr(ghat), wp, _lib.ptr(scratch), scratch.numel(),
                 _lib.stream_ptr()), "pir_mlp_backward_tangent")
+        gws = packed.unpad_grads(gws, ctx.shapes[:nl])
         return (None, None, None, ghat.reshape(ctx.g_out_shape), *gws, *([None] * nl))
 
 

@@ -289,3 +289,37 @@ def test_dino_field_backward_matches_eager(P):
     assert (row > 1e-4).float().mean().item() < 2e-3
     errs = [rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) for k in g0]
     assert float(np.median(errs)) < 5e-4 and max(errs) < 1e-2, errs
+
+
+def test_blend_network_runs_zero_padded_on_the_fused_kernels():
+    """BlendNetwork (128 wide, src/network.py:295-367) runs on the 256-wide engine zero-padded: forward and every
+    gradient against the eager expression."""
+    from pir_amd import scene, mlp_hip
+    _, mats, _ = scene.build_networks(seed=2, device="cuda")
+    net = mats["blend_network"]
+    assert mlp_hip.module_supported(net)
+    g = torch.Generator().manual_seed(4)
+    P = 777
+    dist, rough, cosv = (torch.rand(P, 1, generator=g).cuda() for _ in range(3))
+    w = torch.randn(P, 1, generator=g).cuda()
+    with torch.no_grad():
+        y_inf = net(dist, rough, cosv)
+    res = []
+    for mode in ("fused", "eager"):
+        leaves = [t.clone().requires_grad_(True) for t in (dist, rough, cosv)]
+        net.zero_grad()
+        if mode == "eager":
+            with mlp_hip.eager_grad():
+                y = net(*leaves)
+        else:
+            y = net(*leaves)
+            assert _graph_has(y.grad_fn, "_MlpFn")
+        (y * w).sum().backward()
+        res.append((y.detach(), [t.grad.clone() for t in leaves], {k: p.grad.clone() for k, p in net.named_parameters()}))
+    (y0, l0, g0), (y1, l1, g1) = res
+    assert rel_err(y0.cpu().numpy(), y1.cpu().numpy()) < 2e-5 and rel_err(y_inf.cpu().numpy(), y1.cpu().numpy()) < 2e-5
+    for a, b in zip(l0, l1):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-4
+    for k in g0:
+        assert g0[k].shape == g1[k].shape
+        assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-4, k
