@@ -1,3 +1,5 @@
+"""development aid: fused vs eager material-MLP gradients against a float64 evaluation (calibrates the tolerances of
+tests/test_gpu_mlp.py::test_material_backward_large_vs_float64).  usage: mlp_vs_float64.py P network_name"""
 import sys
 sys.path.insert(0, "/root/repo")
 import torch
