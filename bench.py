@@ -68,7 +68,7 @@ def build_step(res, rank, world, device):
     return step, info, (sdf, mats, dino)
 
 
-def cpu_baseline(res, nets):
+def cpu_baseline(res, nets, repeats=3):
     """The oracle (a port of the reference path) on the host cores: one res x res view of the same scene,
     forward + backward.  Bounded sample: 800^2 does not fit one autograd graph on the CPU."""
     from oracle import pir_oracle as O
@@ -76,10 +76,8 @@ def cpu_baseline(res, nets):
     sdf, mats, dino = nets
     cpu = lambda m: {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}  # noqa: E731
     sdf_state = cpu(sdf)
-    layers = O.mlp_layers(sdf_state)
-    omats = {}
-    for k in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
-        omats[k] = dict(layers=O.mlp_layers(cpu(mats[k])), cfg=scene.MODEL_CONFIG[k])
+    mat_states = {k: cpu(mats[k]) for k in ("diffuse_albedo_network", "specular_albedo_network",
+                                              "specular_roughness_network")}
     odino = dict(layers=O.mlp_layers({k: v.detach().cpu() for k, v in dino.state_dict().items()}),
                  cfg=scene.MODEL_CONFIG["dino_network"])
     tables = O.load_ggx_tables(os.path.join(ROOT, "pir_amd", "renderer", "ggx"))
@@ -87,14 +85,22 @@ def cpu_baseline(res, nets):
     cam = O.CameraRays(res, res, c.K, c.W2C)
     light = torch.tensor(scene.LIGHT_INTENSITY, requires_grad=True)
     off = torch.tensor([list(scene.LIGHT_OFFSET)], requires_grad=True)
-    t0 = time.perf_counter()
-    r = O.render_view(cam, layers, omats, odino, tables, light, light_offset=off,
-                      inv_s=torch.tensor([[scene.INV_S]]), n_vis_samples=128, is_training=True)
-    O.step_loss(r).backward()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(repeats):   # host timings are noisy, report the median of >= 3 runs
+        for t in [light, off] + list(sdf_state.values()) + [v for st in mat_states.values() for v in st.values()]:
+            t.grad = None
+        t0 = time.perf_counter()
+        layers = O.mlp_layers(sdf_state)          # weight norm is part of every reference call (src/network.py:75)
+        omats = {k: dict(layers=O.mlp_layers(st), cfg=scene.MODEL_CONFIG[k]) for k, st in mat_states.items()}
+        r = O.render_view(cam, layers, omats, odino, tables, light, light_offset=off,
+                          inv_s=torch.tensor([[scene.INV_S]]), n_vis_samples=128, is_training=True)
+        O.step_loss(r).backward()
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {"value": res * res / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"one {res}x{res} view of the same scene (same focal/height ratio, {int(r['convergent_mask'].sum())} hits), "
-                      f"trace + visibility(128) + shade fwd+bwd in {dt:.1f} s, torch CPU fp32"}
+                      f"trace + visibility(128) + shade fwd+bwd, median of {repeats} runs = {dt:.1f} s "
+                      f"(all: {', '.join(f'{t:.1f}' for t in times)}), torch CPU fp32"}
 
 
 def main():
@@ -103,8 +109,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--cpu-res", type=int, default=128,
-                    help="side of the view the CPU oracle renders for cpu_baseline (128: about 15-20 s on 16 threads)")
+    ap.add_argument("--cpu-res", type=int, default=96,
+                    help="side of the view the CPU oracle renders for cpu_baseline (96: about 9 s per run on 16 threads)")
+    ap.add_argument("--cpu-repeats", type=int, default=3, help="runs of the CPU baseline; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal "
                                                       "of the multi-process path with every rank on one GPU)")
@@ -203,7 +210,7 @@ def main():
                "roofline": roofline, "kernels": breakdown}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.cpu_res, nets)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_res, nets, args.cpu_repeats)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
