@@ -145,6 +145,23 @@ def test_sdf_backward_chunking_is_consistent():
         assert rel_err(wb.cpu().numpy(), wa.cpu().numpy()) < 1e-5
 
 
+def test_sdf_backward_chunking_with_feature_gradients():
+    """Same as above with an upstream gradient on the 256 features: the caller-owned g_feat rows of every chunk
+    (ragged last chunk included) feed the lin8 weight-gradient jobs directly."""
+    from pir_amd import sdf_hip
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    g = torch.Generator().manual_seed(5)
+    M = 4999
+    x = (torch.rand(M, 3, generator=g) * 2 - 1).cuda()
+    gs, gn = torch.randn(M, generator=g).cuda(), torch.randn(M, 3, generator=g).cuda()
+    gf = torch.randn(M, 256, generator=g).cuda()
+    a = sdf_hip.get_all_backward(net.packed(), x, gs, gf, gn, True, chunk_points=131072)
+    b = sdf_hip.get_all_backward(net.packed(), x, gs, gf, gn, True, chunk_points=2048)
+    assert torch.equal(a[2], b[2])
+    for wa, wb in zip(a[0] + a[1], b[0] + b[1]):
+        assert rel_err(wb.cpu().numpy(), wa.cpu().numpy()) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------- visibility
 @pytest.mark.parametrize("n_samples", [128, 256])
 def test_light_visibility_matches_reference(n_samples):
