@@ -15,7 +15,9 @@ import os
 import sys
 
 NAMES = {"sdf_eval_kernel<2>": "sdf_eval_kernel(get_all)", "sdf_eval_kernel<0>": "sdf_eval_kernel(forward)",
-         "bwd_sweep_kernel": "bwd_sweep_kernel", "wgrad_kernel": "wgrad_kernel"}
+         "pir::bwd_sweep_kernel": "bwd_sweep_kernel", "wgrad_kernel": "wgrad_kernel",
+         "mlp_eval_kernel": "mlp_eval_kernel", "mlp_bwd_sweep_kernel": "mlp_bwd_sweep_kernel"}
+SUFFIX = os.environ.get("PMC_SUFFIX", "")     # e.g. "(diffuse)": one entry per profiled network
 
 
 def per_launch(path, counter):
@@ -27,6 +29,7 @@ def per_launch(path, counter):
             if frag in r["Kernel_Name"]:
                 tot[name] += float(r["Counter_Value"]) * 1024.0
                 n[name] += 1
+                break
     return {k: tot[k] / n[k] for k in tot}, n
 
 
@@ -37,10 +40,12 @@ def main():
     out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     for k in fetch:
+        if SUFFIX and not k.startswith("mlp_"):
+            continue
         n = min(pts, 131072.0) if k in ("bwd_sweep_kernel", "wgrad_kernel") else pts
-        out[k] = {"points_per_launch": n, "fetch_bytes_corrected": 2.0 * fetch[k], "write_bytes": write.get(k, 0.0),
+        out[k + SUFFIX] = {"points_per_launch": n, "fetch_bytes_corrected": 2.0 * fetch[k], "write_bytes": write.get(k, 0.0),
                   "hbm_bytes_per_point": (2.0 * fetch[k] + write.get(k, 0.0)) / n}
-        print(k, out[k], "dispatches", nf[k])
+        print(k + SUFFIX, out[k + SUFFIX], "dispatches", nf[k])
     json.dump(out, open(out_path, "w"), indent=1)
 
 
