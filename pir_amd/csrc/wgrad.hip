@@ -70,11 +70,17 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __
   };
   if (nsteps > 0) fetch(0);
   for (int step = 0; step < nsteps; ++step) {
+#ifdef PIR_ABL_WG_NOSTAGE   // ablation: operands stay in LDS, no barriers, no refetch
+    if (step == 0) { store_tile(Xs, tx); store_tile(Ys, ty); __syncthreads(); }
+#else
     __syncthreads();
     store_tile(Xs, tx);
     store_tile(Ys, ty);
     __syncthreads();
+#ifndef PIR_ABL_WG_NOFETCH
     if (step + 1 < nsteps) fetch(step + 1);
+#endif
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (jb.bias && step % nprod == 0) {
       const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
