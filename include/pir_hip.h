@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-enum { PIR_OK = 0, PIR_ERR_ARG = 1, PIR_ERR_LAUNCH = 2, PIR_ERR_SCRATCH = 3 };
+enum { PIR_OK = 0, PIR_ERR_ARG = 1, PIR_ERR_LAUNCH = 2, PIR_ERR_SCRATCH = 3, PIR_ERR_TOO_LARGE = 4 };
 
 /* ---- SDF network (src/network.py:8-142, SDFNetwork with the configs/model_config.json architecture:
  *      d_in 3, multires 6, 8 x 256 softplus(beta=100), skip at 4, d_out 257) ------------------------- */
@@ -73,6 +73,20 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
 
 /* Synchronising read-back of the tracer status word (*host_status: 0 ok, 1 bisection bound hit). */
 int pir_trace_status(const void* workspace, int* host_status, void* stream);
+
+/* pir_trace for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs and results as pir_trace,
+ * but the tracer workspace is a 2.1 MB array inside the library's device image (one copy per GPU, held until the
+ * process ends) and the call performs no allocation of any kind.  Limits: n_rays <= PIR_TRACE_STATIC_MAX_RAYS
+ * (a 256 x 256 view: the largest training patch, render_surface.py:556-559) and at most 64 chunks, else
+ * PIR_ERR_TOO_LARGE.  status: optional DEVICE int that receives the tracer status word (0 ok, 1 bisection bound
+ * hit) in stream order, since there is no caller workspace for pir_trace_status to read.  All calls on one GPU share
+ * that GPU's array: calls that overlap on one GPU (different streams or threads) race; calls on one stream are safe. */
+#define PIR_TRACE_STATIC_MAX_RAYS 65536L
+int pir_trace_static(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
+                     const float* max_dis, const unsigned char* work_mask, float sdf_threshold,
+                     int sphere_tracing_iters, int n_steps, long chunk, int max_bisect, unsigned char* convergent,
+                     float* points, float* sdf, float* distance, int* status, void* stream);
 
 /* Camera.get_rays + intersect_sphere (raytracer.py:305-326, :253-273).  uv [n,2] or NULL for the pixel
  * centres of a width-wide image; cam21 = K_inv[:3,:3] (9) | C2W[:3,:3] (9) | C2W[:3,3] (3). */

@@ -52,6 +52,8 @@ def _declare(L):
     L.pir_trace_workspace_bytes.argtypes = [lg, lg, i32]
     L.pir_trace.restype = i32
     L.pir_trace.argtypes = [vp, lg, vp, vp, vp, vp, vp, f32, i32, i32, lg, i32, vp, vp, vp, vp, vp, sz, vp]
+    L.pir_trace_static.restype = i32
+    L.pir_trace_static.argtypes = [vp, lg, vp, vp, vp, vp, vp, f32, i32, i32, lg, i32, vp, vp, vp, vp, vp, vp]
     L.pir_trace_status.restype = i32
     L.pir_trace_status.argtypes = [vp, ctypes.POINTER(i32), vp]
     L.pir_camera_rays.restype = i32

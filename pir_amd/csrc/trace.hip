@@ -6,6 +6,7 @@
 // ray state arithmetic uses un-contracted mul/add so it rounds like the eager PyTorch ops it replaces.
 #include "sdf_sweeps.cuh"
 #include "pir_common.h"
+#include <mutex>
 
 namespace pir {
 
@@ -299,23 +300,16 @@ size_t pir_trace_workspace_bytes(long n_rays, long chunk, int max_bisect) {
   return ws_layout(n_rays, nchunks, max_bisect, nullptr, nullptr);
 }
 
-int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
-              const float* max_dis, const unsigned char* work_mask, float sdf_threshold, int sphere_tracing_iters,
-              int n_steps, long chunk, int max_bisect, unsigned char* convergent, float* points, float* sdf,
-              float* distance, void* workspace, size_t workspace_bytes, void* stream_) {
-  if (n_rays < 0 || n_rays > 0x7fffffffL / 4) return PIR_ERR_ARG;
-  if (n_rays == 0) return PIR_OK;
-  if (!packed || !ray_o || !ray_d || !min_dis || !max_dis || !work_mask || !convergent || !points || !sdf ||
-      !distance || !workspace)
-    return PIR_ERR_ARG;
-  if (sphere_tracing_iters < 0 || sphere_tracing_iters > 30 || n_steps < 2 || max_bisect < 1 || max_bisect > 64)
-    return PIR_ERR_ARG;
-  if (chunk <= 0) chunk = n_rays;
-  const int nchunks = (int)((n_rays + chunk - 1) / chunk);
-  if (workspace_bytes < ws_layout(n_rays, nchunks, max_bisect, nullptr, nullptr)) return PIR_ERR_SCRATCH;
+// Enqueues the whole tracer on `stream` over a workspace laid out by ws_layout at `workspace` (arguments checked by
+// the callers).
+static int trace_enqueue(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
+                         const float* max_dis, const unsigned char* work_mask, float sdf_threshold,
+                         int sphere_tracing_iters, int n_steps, long chunk, int nchunks, int max_bisect,
+                         unsigned char* convergent, float* points, float* sdf, float* distance, char* workspace,
+                         void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   TraceWs ws;
-  ws_layout(n_rays, nchunks, max_bisect, (char*)workspace, &ws);
+  ws_layout(n_rays, nchunks, max_bisect, workspace, &ws);
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
@@ -346,6 +340,88 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
                        ws);
   }
   return pir_check_launch();
+}
+
+static int trace_check_args(const void* packed, long n_rays, const float* ray_o, const float* ray_d,
+                            const float* min_dis, const float* max_dis, const unsigned char* work_mask,
+                            int sphere_tracing_iters, int n_steps, int max_bisect, const unsigned char* convergent,
+                            const float* points, const float* sdf, const float* distance) {
+  if (n_rays < 0 || n_rays > 0x7fffffffL / 4) return PIR_ERR_ARG;
+  if (n_rays == 0) return PIR_OK;
+  if (!packed || !ray_o || !ray_d || !min_dis || !max_dis || !work_mask || !convergent || !points || !sdf || !distance)
+    return PIR_ERR_ARG;
+  if (sphere_tracing_iters < 0 || sphere_tracing_iters > 30 || n_steps < 2 || max_bisect < 1 || max_bisect > 64)
+    return PIR_ERR_ARG;
+  return PIR_OK;
+}
+
+int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
+              const float* max_dis, const unsigned char* work_mask, float sdf_threshold, int sphere_tracing_iters,
+              int n_steps, long chunk, int max_bisect, unsigned char* convergent, float* points, float* sdf,
+              float* distance, void* workspace, size_t workspace_bytes, void* stream_) {
+  const int rc = trace_check_args(packed, n_rays, ray_o, ray_d, min_dis, max_dis, work_mask, sphere_tracing_iters,
+                                  n_steps, max_bisect, convergent, points, sdf, distance);
+  if (rc != PIR_OK || n_rays == 0) return rc;
+  if (!workspace) return PIR_ERR_ARG;
+  if (chunk <= 0) chunk = n_rays;
+  const int nchunks = (int)((n_rays + chunk - 1) / chunk);
+  if (workspace_bytes < ws_layout(n_rays, nchunks, max_bisect, nullptr, nullptr)) return PIR_ERR_SCRATCH;
+  return trace_enqueue(packed, n_rays, ray_o, ray_d, min_dis, max_dis, work_mask, sdf_threshold, sphere_tracing_iters,
+                       n_steps, chunk, nchunks, max_bisect, convergent, points, sdf, distance, (char*)workspace, stream_);
+}
+
+// ---- allocation-free variant ----------------------------------------------------------------------------------
+// The tracer workspace (active lists, bisection brackets, counters) of pir_trace_static lives in this file-scope
+// device array instead of caller memory.  Every GPU the library runs on holds its own copy at its own address; the
+// host-side name below is only a handle for hipGetSymbolAddress, never a kernel argument.
+constexpr long kStaticMaxRays = PIR_TRACE_STATIC_MAX_RAYS;
+constexpr int kStaticMaxChunks = 64;
+constexpr size_t kStaticHeader = (sizeof(int) * (kNumCounters + (64 + 2) * kStaticMaxChunks) + 255) & ~(size_t)255;
+constexpr size_t kStaticBytes = kStaticHeader + 8 * sizeof(int) * kStaticMaxRays + kStaticMaxRays;   // 2 179 840
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+static std::mutex g_static_mu;
+static char* g_static_ptr[64] = {nullptr};   // per device: address of that device's copy of `scratch`
+
+// Device address of the current device's `scratch`, looked up once per device.
+static char* static_workspace() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_static_mu);
+  if (!g_static_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || !p) return nullptr;
+    g_static_ptr[dev] = (char*)p;
+  }
+  return g_static_ptr[dev];
+}
+
+int pir_trace_static(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
+                     const float* max_dis, const unsigned char* work_mask, float sdf_threshold,
+                     int sphere_tracing_iters, int n_steps, long chunk, int max_bisect, unsigned char* convergent,
+                     float* points, float* sdf, float* distance, int* status, void* stream_) {
+  const int rc = trace_check_args(packed, n_rays, ray_o, ray_d, min_dis, max_dis, work_mask, sphere_tracing_iters,
+                                  n_steps, max_bisect, convergent, points, sdf, distance);
+  if (rc != PIR_OK) return rc;
+  if (n_rays > kStaticMaxRays) return PIR_ERR_TOO_LARGE;
+  if (n_rays == 0) {
+    if (status && hipMemsetAsync(status, 0, sizeof(int), (hipStream_t)stream_) != hipSuccess) return PIR_ERR_LAUNCH;
+    return PIR_OK;
+  }
+  if (chunk <= 0) chunk = n_rays;
+  const int nchunks = (int)((n_rays + chunk - 1) / chunk);
+  if (nchunks > kStaticMaxChunks) return PIR_ERR_TOO_LARGE;
+  if (ws_layout(n_rays, nchunks, max_bisect, nullptr, nullptr) > kStaticBytes) return PIR_ERR_TOO_LARGE;
+  char* ws = static_workspace();
+  if (!ws) return PIR_ERR_LAUNCH;
+  const int rc2 = trace_enqueue(packed, n_rays, ray_o, ray_d, min_dis, max_dis, work_mask, sdf_threshold,
+                                sphere_tracing_iters, n_steps, chunk, nchunks, max_bisect, convergent, points, sdf,
+                                distance, ws, stream_);
+  if (rc2 != PIR_OK) return rc2;
+  if (status && hipMemcpyAsync(status, (const int*)ws + kCntStatus, sizeof(int), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream_) != hipSuccess)
+    return PIR_ERR_LAUNCH;
+  return PIR_OK;
 }
 
 int pir_trace_status(const void* workspace, int* host_status, void* stream_) {

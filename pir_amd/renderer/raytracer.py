@@ -89,6 +89,28 @@ class RayTracer(nn.Module):
         return {"convergent_mask": conv.bool().reshape(shp), "points": pts.reshape(*shp, 3),
                 "sdf": sdf.reshape(shp), "distance": dis.reshape(shp)}
 
+    @torch.no_grad()
+    def forward_static(self, sdf, ray_o, ray_d, min_dis, max_dis, work_mask, out, status=None, chunk=None):
+        """`forward` for callers that must not allocate device memory (HIP graph capture, serving loops): runs
+        pir_trace_static, whose workspace lives inside the library (<= 65 536 rays).  Inputs must already be
+        contiguous fp32 / uint8 CUDA tensors; `out` holds the preallocated results: convergent_mask uint8 [n],
+        points [n,3], sdf [n], distance [n]; `status`: optional int32 [1] device tensor (1 = bisection bound hit)."""
+        net = sdf.sdf_network
+        n = min_dis.numel()
+        for t, dt in ((ray_o, torch.float32), (ray_d, torch.float32), (min_dis, torch.float32),
+                      (max_dis, torch.float32), (work_mask, torch.uint8), (out["convergent_mask"], torch.uint8),
+                      (out["points"], torch.float32), (out["sdf"], torch.float32), (out["distance"], torch.float32)):
+            assert t.is_cuda and t.is_contiguous() and t.dtype == dt, "forward_static takes contiguous fp32/uint8 CUDA tensors"
+        assert out["points"].numel() == 3 * n and out["sdf"].numel() == n and out["distance"].numel() == n
+        with torch.cuda.device(ray_o.device):
+            _lib.check(_lib.lib().pir_trace_static(
+                _lib.ptr(net.packed().buf), n, _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(min_dis), _lib.ptr(max_dis),
+                _lib.ptr(work_mask), float(self.sdf_threshold), int(self.sphere_tracing_iters), int(self.n_steps),
+                int(chunk) if chunk else 0, int(self.max_bisect), _lib.ptr(out["convergent_mask"]),
+                _lib.ptr(out["points"]), _lib.ptr(out["sdf"]), _lib.ptr(out["distance"]), _lib.ptr(status),
+                _lib.stream_ptr()), "pir_trace_static")
+        return out
+
     def trace_status(self, device):
         """Synchronising check that the last native trace on `device` did not hit the bisection bound."""
         ws = _trace_ws.get(torch.device(device).index)
