@@ -47,7 +47,11 @@ def build_step(res, rank, world, device):
                                   {"params": list(pl.light_offset.parameters()), "lr": 1e-4}]))
     params = [p for o in opts for g in o.param_groups for p in g["params"]]
     bucket = FlatGradBucket(params) if world > 1 else None
-    info = {}
+    info = {"hits_first": None, "checked_status": 0}
+    # The scene is frozen: the optimizer step (and the weight re-pack it triggers) executes every step, then the
+    # parameters are restored from a device-side snapshot, so every timed step does the same work on the same
+    # geometry (training on sum(color * vis) would otherwise shrink the object from step to step).
+    snapshot = [p.detach().clone() for p in params]
 
     def step():
         for o in opts:
@@ -62,15 +66,48 @@ def build_step(res, rank, world, device):
             bucket.all_reduce()
         for o in opts:
             o.step()
+        with torch.no_grad():
+            torch._foreach_copy_(params, snapshot)      # in-place: bumps the versions, the kernels re-pack
         info["hits"] = results["convergent_mask"]
+        if info["hits_first"] is None:
+            info["hits_first"] = results["convergent_mask"].clone()
         info["loss"] = loss.detach()
+        info["tracer"] = tracer
 
     return step, info, (sdf, mats, dino)
 
 
-def cpu_baseline(res, nets, repeats=3):
-    """The oracle (a port of the reference path) on the host cores: one res x res view of the same scene,
-    forward + backward.  Bounded sample: 800^2 does not fit one autograd graph on the CPU."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+def pick_tiles(hit_mask, tile, n_tiles):
+    """n_tiles tiles of a tile x tile grid over the view whose joint hit fraction is closest to the whole view's
+    (so that rays/s of the sample estimates rays/s of the view).  Returns [(row, col)] upper-left corners."""
+    import itertools
+    H, W = hit_mask.shape
+    r0, c0 = (H % tile) // 2, (W % tile) // 2
+    cells = [(r, c) for r in range(r0, H - tile + 1, tile) for c in range(c0, W - tile + 1, tile)]
+    frac = [float(hit_mask[r:r + tile, c:c + tile].float().mean()) for r, c in cells]
+    target = float(hit_mask.float().mean())
+    if len(cells) <= n_tiles:
+        return cells, target, target
+    best = min(itertools.combinations(range(len(cells)), n_tiles),
+               key=lambda ix: (abs(sum(frac[i] for i in ix) / n_tiles - target), ix))
+    return [cells[i] for i in best], sum(frac[i] for i in best) / n_tiles, target
+
+
+def cpu_baseline(res, nets, hit_mask, tile=128, n_tiles=4, repeats=3):
+    """The oracle (a port of the reference path) on the host cores, as BASELINE.md section 3 prescribes: the res x res
+    view does not fit one autograd graph on the CPU, so it is rendered as tile x tile crops of the same camera with a
+    backward per tile and gradient accumulation (a sum loss: identical maths); n_tiles tiles are timed and scaled by
+    ray count; the median of `repeats` passes is reported."""
     from oracle import pir_oracle as O
     from pir_amd import scene
     sdf, mats, dino = nets
@@ -82,25 +119,41 @@ def cpu_baseline(res, nets, repeats=3):
                  cfg=scene.MODEL_CONFIG["dino_network"])
     tables = O.load_ggx_tables(os.path.join(ROOT, "pir_amd", "renderer", "ggx"))
     c = scene.make_camera(res, res)
-    cam = O.CameraRays(res, res, c.K, c.W2C)
+    tile = min(tile, res)
+    cells, frac, target = pick_tiles(hit_mask.cpu(), tile, n_tiles)
+    cams = []
+    for r, col in cells:      # Camera.crop_region (raytracer.py:358-383): the principal point moves, nothing else
+        K = c.K.clone()
+        K[0, 2] -= col
+        K[1, 2] -= r
+        cams.append(O.CameraRays(tile, tile, K, c.W2C))
     light = torch.tensor(scene.LIGHT_INTENSITY, requires_grad=True)
     off = torch.tensor([list(scene.LIGHT_OFFSET)], requires_grad=True)
-    times = []
+    times, hits = [], 0
     for _ in range(repeats):   # host timings are noisy, report the median of >= 3 runs
         for t in [light, off] + list(sdf_state.values()) + [v for st in mat_states.values() for v in st.values()]:
             t.grad = None
+        hits = 0
         t0 = time.perf_counter()
-        layers = O.mlp_layers(sdf_state)          # weight norm is part of every reference call (src/network.py:75)
-        omats = {k: dict(layers=O.mlp_layers(st), cfg=scene.MODEL_CONFIG[k]) for k, st in mat_states.items()}
-        r = O.render_view(cam, layers, omats, odino, tables, light, light_offset=off,
-                          inv_s=torch.tensor([[scene.INV_S]]), n_vis_samples=128, is_training=True)
-        O.step_loss(r).backward()
+        for i_cam, cam in enumerate(cams):
+            print(f"[bench] cpu_baseline pass {len(times) + 1}/{repeats} tile {i_cam + 1}/{len(cams)} "
+                  f"({time.perf_counter() - t0:.0f} s)", file=sys.stderr, flush=True)   # a long silent run looks hung
+            layers = O.mlp_layers(sdf_state)      # weight norm is part of every reference call (src/network.py:75)
+            omats = {k: dict(layers=O.mlp_layers(st), cfg=scene.MODEL_CONFIG[k]) for k, st in mat_states.items()}
+            r = O.render_view(cam, layers, omats, odino, tables, light, light_offset=off,
+                              inv_s=torch.tensor([[scene.INV_S]]), n_vis_samples=128, is_training=True)
+            O.step_loss(r).backward()             # per-tile backward, gradients accumulate
+            hits += int(r["convergent_mask"].sum())
         times.append(time.perf_counter() - t0)
     dt = sorted(times)[len(times) // 2]
-    return {"value": res * res / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"one {res}x{res} view of the same scene (same focal/height ratio, {int(r['convergent_mask'].sum())} hits), "
-                      f"trace + visibility(128) + shade fwd+bwd, median of {repeats} runs = {dt:.1f} s "
-                      f"(all: {', '.join(f'{t:.1f}' for t in times)}), torch CPU fp32"}
+    rays = len(cams) * tile * tile
+    return {"value": rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(cams)} tiles of {tile}x{tile} rays cropped from the {res}x{res} view (corners {cells}; "
+                      f"{hits} hits = {hits / rays:.3f} of the sample's rays, whole view {target:.3f}), per-tile "
+                      f"trace + visibility(128) + shade fwd+bwd with gradient accumulation, initial weights; "
+                      f"rays/s = sample rays / median of {repeats} passes = {dt:.1f} s (all: "
+                      f"{', '.join(f'{t:.1f}' for t in times)}); {_cpu_model()}, {torch.get_num_threads()} threads, "
+                      f"torch CPU fp32"}
 
 
 def main():
@@ -109,8 +162,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--res", type=int, default=800)
-    ap.add_argument("--cpu-res", type=int, default=96,
-                    help="side of the view the CPU oracle renders for cpu_baseline (96: about 9 s per run on 16 threads)")
+    ap.add_argument("--cpu-tile", type=int, default=128, help="side of the tiles the CPU oracle renders (BASELINE.md 3)")
+    ap.add_argument("--cpu-tiles", type=int, default=4, help="tiles timed per pass of the CPU baseline")
     ap.add_argument("--cpu-repeats", type=int, default=3, help="runs of the CPU baseline; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal "
@@ -196,6 +249,14 @@ def main():
     breakdown = {names[i]: {"launches": int(launches[i]), "ms_per_step": round(total_ms[i] / args.steps, 3)}
                  for i in range(nk) if launches[i]}
 
+    # the workload must be the same at every step (frozen scene) and every hit point converged
+    if not torch.equal(info["hits"], info["hits_first"]):
+        raise SystemExit("bench: the hit mask changed between the first and the last step (scene not frozen)")
+    info["tracer"].check_status()
+    from pir_amd import sdf_autograd
+    hits = int(info["hits"].sum().item())
+    nz = sdf_autograd.stats.get("last_nonzero_fraction")
+
     if rank == 0:
         rays = args.res * args.res * world * args.steps
         out = {"metric": "rays/sec fwd+bwd (trace+GGX+shadow) at 800x800", "value": round(rays / dt, 1),
@@ -205,12 +266,16 @@ def main():
                "config": {"workload": f"{args.res}x{args.res} view per GPU: sphere trace + light-visibility march "
                                       "(128 samples) + GGX shade, fwd+bwd + Adam step, random-init nets "
                                       "(configs/model_config.json), offset point light",
-                          "views": world, "hits_per_view": int(info["hits"].sum().item()),
+                          "views": world, "hits_per_view": hits, "scene": "frozen (parameters restored after "
+                          "every Adam step; hit mask identical at the first and the last step)",
+                          "march_samples_per_view": hits * 118,
+                          "backward_march_samples_per_view": None if nz is None else int(round(nz * hits * 118)),
                           "parallelism": f"dp{world} (one view per GPU, flat RCCL grad all-reduce)"},
                "roofline": roofline, "kernels": breakdown}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()
-            out["cpu_baseline"] = cpu_baseline(args.cpu_res, nets, args.cpu_repeats)
+            out["cpu_baseline"] = cpu_baseline(args.res, nets, info["hits"], args.cpu_tile, args.cpu_tiles,
+                                               args.cpu_repeats)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

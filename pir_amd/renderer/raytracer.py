@@ -62,7 +62,20 @@ class RayTracer(nn.Module):
         self.sphere_tracing_iters = sphere_tracing_iters
         self.n_steps = n_steps
         self.max_num_pts = max_num_pts
-        self.max_bisect = 12   # bisection rounds enqueued by the HIP path (8 are needed for unit-sphere rays)
+        # Bisection rounds the HIP path enqueues.  The reference halves until every bracket is below 2*threshold
+        # (raytracer.py:229-250); a bracket starts at span/(n_steps-1), so ceil(log2(span/((n_steps-1) 2 thr))) rounds
+        # finish it.  The count below covers spans up to 1024 (unit-sphere rays have span <= 2, the indirect bounce
+        # <= 3); rounds with nothing left to do are skipped on the device, so the margin is free.  Should the bound
+        # ever be hit the kernels raise a status word that is accumulated per device and checked by check_status().
+        self.max_bisect = self.bisect_rounds_for(1024.0)
+        self._status = {}      # device index -> int32[1] tensor: OR of the status words of every trace so far
+
+    def bisect_rounds_for(self, span):
+        """Rounds after which a bracket of span/(n_steps-1) is below 2*sdf_threshold, plus one; within the C ABI's 1..64."""
+        import math
+        first = float(span) / max(1, self.n_steps - 1)
+        rounds = math.ceil(math.log2(max(first / (2.0 * self.sdf_threshold), 1.0))) + 1
+        return int(min(64, max(1, rounds)))
 
     # ---------------------------------------------------------------- native path
     def _trace_hip(self, net, ray_o, ray_d, min_dis, max_dis, work_mask, chunk):
@@ -86,6 +99,11 @@ class RayTracer(nn.Module):
                                    int(self.n_steps), chunk, int(self.max_bisect), _lib.ptr(conv), _lib.ptr(pts),
                                    _lib.ptr(sdf), _lib.ptr(dis), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                        "pir_trace")
+        # accumulate the tracer status word (counter 33 of the workspace header) on the device: no host sync here
+        acc = self._status.get(dev.index)
+        if acc is None:
+            acc = self._status[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+        acc.bitwise_or_(ws[:256].view(torch.int32)[33:34])
         return {"convergent_mask": conv.bool().reshape(shp), "points": pts.reshape(*shp, 3),
                 "sdf": sdf.reshape(shp), "distance": dis.reshape(shp)}
 
@@ -110,6 +128,23 @@ class RayTracer(nn.Module):
                 _lib.ptr(out["points"]), _lib.ptr(out["sdf"]), _lib.ptr(out["distance"]), _lib.ptr(status),
                 _lib.stream_ptr()), "pir_trace_static")
         return out
+
+    def check_status(self, device=None, reset=True):
+        """Synchronising check, meant once per training step / rendered image (not per trace): raises if any native
+        trace since the last check ran out of bisection rounds, i.e. returned brackets wider than 2*sdf_threshold
+        where the reference would have kept halving."""
+        bad = []
+        for idx, acc in self._status.items():
+            if device is not None and torch.device(device).index not in (None, idx):
+                continue
+            if int(acc.item()) != 0:
+                bad.append(idx)
+            if reset:
+                acc.zero_()
+        if bad:
+            raise RuntimeError(
+                f"RayTracer: the bisection bound (max_bisect={self.max_bisect}) was hit on device(s) {bad}: some hit "
+                "points are not converged to 2*sdf_threshold.  Raise RayTracer.max_bisect (<= 64) and trace again.")
 
     def trace_status(self, device):
         """Synchronising check that the last native trace on `device` did not hit the bisection bound."""

@@ -207,4 +207,7 @@ def training_step(state, global_step, eik_points=None):
                       img_ssim_loss=f(img_ssim), eik_loss=f(eik_loss), roughrange_loss=f(roughrange_loss),
                       smoothness_loss=f(smoothness_loss), idx=idx, camera_crop=camera_crop, results=results,
                       convergent_mask=convergent_mask, render_shadow=render_shadow)
+    # the float() reads above synchronised the stream: reading the accumulated tracer status costs no extra wait
+    if hasattr(state.raytracer, "check_status"):
+        state.raytracer.check_status()
     return state.last

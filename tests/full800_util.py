@@ -1,0 +1,54 @@
+"""Shared pieces of the full-size parity tests: element-wise error criterion with fp64 adjudication, and the
+regenerated full-size material networks of shade_points.npz."""
+import numpy as np
+
+TOL = 1e-4      # north_star: depth / normal / radiance / gradients within 1e-4 relative
+
+
+def elem_err(got, ref, floor=None):
+    """max over elements of |got - ref| / (|ref| + floor); floor defaults to mean|ref| of the tensor (gradient
+    tensors are full of near-zero entries, a pure element-relative error is meaningless there)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    if ref.size == 0:
+        return 0.0
+    if floor is None:
+        floor = np.abs(ref).mean() + 1e-300
+    return float((np.abs(got - ref) / (np.abs(ref) + floor)).max())
+
+
+def judge(name, got, ref32, ref64, report, tol=TOL, slack=2.0):
+    """Bar (1): got within `tol` of the fp32 reference, element-wise.  Where that is missed, bar (2) adjudicates with
+    the fp64 run of the same reference code: got must be no farther from fp64 than `slack` x the fp32 reference is.
+    Appends (name, err vs ref32, err of got vs fp64, err of ref32 vs fp64, verdict) to `report`."""
+    floor = np.abs(np.asarray(ref64, np.float64)).mean() + 1e-300
+    e32 = elem_err(got, ref32, floor)
+    e_got = elem_err(got, ref64, floor)
+    e_ref = elem_err(ref32, ref64, floor)
+    ok = e32 <= tol or e_got <= max(slack * e_ref, tol)
+    report.append((name, e32, e_got, e_ref, "ok" if e32 <= tol else ("ok-fp64" if ok else "FAIL")))
+    return ok
+
+
+def print_report(report, title):
+    print(f"\n{title}: tensor | err vs fp32 ref | err vs fp64 | fp32 ref vs fp64")
+    for name, e32, eg, er, verdict in report:
+        print(f"  {name:58s} {e32:9.2e} {eg:9.2e} {er:9.2e}  {verdict}")
+
+
+def full_materials(device, dtype=None):
+    """Full-size material / DINO networks with the weights tools/gen_golden_full800.py used (fill_state seeds)."""
+    import torch
+    import materials_util as MU
+    from pir_amd import scene
+    from pir_amd.network import RenderingNetwork, PointLightNetwork, DINONetwork
+    nets = {}
+    for i, nm in enumerate(MU.NAMES[:3]):
+        nets[nm] = RenderingNetwork(**scene.MODEL_CONFIG[nm])
+        nets[nm].load_state_dict(MU.fill_state(nets[nm].state_dict(), seed=100 + i))
+    pl = PointLightNetwork(enable_offset=True)
+    pl.set_light(135.0)
+    pl.light_offset.weight.data = torch.tensor([[0.2, 0.1, 0.0]])
+    nets["point_light_network"] = pl
+    dino = DINONetwork(**scene.MODEL_CONFIG["dino_network"])
+    dino.load_state_dict(MU.fill_state(dino.state_dict(), seed=103))
+    return {k: v.to(device) for k, v in nets.items()}, dino.to(device)

@@ -1,0 +1,92 @@
+"""Direct C-ABI checks of the small entry points against the reference fixtures and of
+the tracer's bisection bound (row a7: the reference loops until every bracket is below 2*threshold)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from gpu_util import sdf_net
+
+pytestmark = pytest.mark.gpu
+
+
+def _elem_rel(got, ref, floor):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    return float((np.abs(got - ref) / (np.abs(ref) + floor)).max())
+
+
+@pytest.mark.parametrize("mode", ["uv", "pixel_grid"])
+def test_camera_rays_abi_matches_reference(mode):
+    """pir_camera_rays vs Camera.get_rays + intersect_sphere captured from the reference (camera.npz)."""
+    from pir_amd import _lib
+    d = load_golden("camera.npz")
+    W, H = int(d["W"]), int(d["H"])
+    n = W * H
+    K, W2C = torch.from_numpy(d["K"]).double(), torch.from_numpy(d["W2C"]).double()
+    K_inv, C2W = torch.inverse(K), torch.inverse(W2C)
+    cam21 = torch.cat([K_inv[:3, :3].reshape(-1), C2W[:3, :3].reshape(-1), C2W[:3, 3].reshape(-1)]).float().cuda()
+    uv = torch.from_numpy(d["uv"]).reshape(-1, 2).contiguous().cuda()
+    o, dd = torch.empty(n, 3, device="cuda"), torch.empty(n, 3, device="cuda")
+    nrm, lo, hi = torch.empty(n, device="cuda"), torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    hit = torch.empty(n, dtype=torch.uint8, device="cuda")
+    P = _lib.ptr
+    rc = _lib.lib().pir_camera_rays(n, W, P(uv) if mode == "uv" else None, P(cam21), 1.0, P(o), P(dd), P(nrm), P(hit),
+                                    P(lo), P(hi), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    errs = {"ray_o": np.abs(o.cpu().numpy() - d["ray_o"].reshape(-1, 3)).max(),
+            "ray_d": np.abs(dd.cpu().numpy() - d["ray_d"].reshape(-1, 3)).max(),      # unit vectors: absolute
+            "ray_d_norm": _elem_rel(nrm.cpu().numpy(), d["ray_d_norm"].reshape(-1), 1e-12)}
+    m = d["mask"].astype(bool)
+    assert np.array_equal(hit.cpu().numpy().astype(bool), m)
+    errs["min_dis"] = _elem_rel(lo.cpu().numpy()[m], d["min_dis"][m], 1e-3)
+    errs["max_dis"] = _elem_rel(hi.cpu().numpy()[m], d["max_dis"][m], 1e-3)
+    print("camera_rays", mode, errs)
+    assert errs["ray_o"] == 0.0
+    assert errs["ray_d"] < 2e-7 and errs["ray_d_norm"] < 2e-7
+    # the sphere interval is a difference of nearly equal numbers for grazing rays: 1e-5 element-relative
+    assert errs["min_dis"] < 1e-5 and errs["max_dis"] < 1e-5
+
+
+def test_reparam_points_gpu_matches_reference():
+    """reparam_points value and gradient on the GPU vs reparam.npz (raytracer.py:18-25)."""
+    from pir_amd.renderer.raytracer import reparam_points
+    d = load_golden("reparam.npz")
+    t = lambda k: torch.from_numpy(d[k]).cuda()  # noqa: E731
+    sdf = t("sdf").requires_grad_(True)
+    out = reparam_points(t("points"), t("grads"), t("dirs"), sdf)
+    assert torch.equal(out.detach().cpu(), torch.from_numpy(d["out"]))           # value-identical to the points
+    (out * t("cw")).sum().backward()
+    e = _elem_rel(sdf.grad.cpu().numpy(), d["g_sdf"], 1e-6 * np.abs(d["g_sdf"]).max())
+    print("reparam grad element-relative", e)
+    assert e < 2e-6
+
+
+def test_bisection_runs_as_many_rounds_as_the_reference():
+    """A 381-long sampler interval starts bisection from a 3.0-wide bracket: 15 halvings to reach 2*5e-5 (the old
+    fixed bound of 12 would have stopped at 7e-4).  The HIP tracer must agree with the loop-until-done reference
+    logic (RayTracer._trace_torch on the same SDF kernels) and report a clean status; with the bound forced down to
+    12 rounds the status check must raise."""
+    from pir_amd.renderer.raytracer import RayTracer, SdfCallable
+    net = sdf_net("sdf_full.npz")
+    n = 300
+    g = torch.Generator().manual_seed(2)
+    o = torch.tensor([[0.0, 0.0, -3.0]]).repeat(n, 1)
+    o[:, :2] += 0.2 * (torch.rand(n, 2, generator=g) - 0.5)
+    o, d = o.cuda(), torch.tensor([[0.0, 0.0, 1.0]], device="cuda").repeat(n, 1)
+    lo, hi = torch.zeros(n, device="cuda"), torch.full((n,), 381.0, device="cuda")
+    work = torch.ones(n, dtype=torch.bool, device="cuda")
+    tr = RayTracer(sphere_tracing_iters=0)           # every ray goes to the sampler
+    assert tr.max_bisect >= 15
+    ref = tr._trace_torch(SdfCallable(net), o, d, lo.clone(), hi.clone(), work)
+    got = tr(SdfCallable(net), o, d, lo, hi, work)
+    tr.check_status()                                 # clean
+    assert bool(ref["convergent_mask"].all()) and torch.equal(got["convergent_mask"], ref["convergent_mask"])
+    err = (got["distance"] - ref["distance"]).abs().max().item()
+    print("bisection distance error", err, "sdf at the hit", got["sdf"].abs().max().item())
+    assert err <= 1e-4 and got["sdf"].abs().max().item() < 2e-4
+    tr.max_bisect = 12
+    tr(SdfCallable(net), o, d, lo, hi, work)
+    with pytest.raises(RuntimeError, match="bisection bound"):
+        tr.check_status()
+    tr.check_status()                                 # the flag was reset by the failed check

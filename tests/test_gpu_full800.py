@@ -1,0 +1,128 @@
+"""Full-size parity against the reference (tools/gen_golden_full800.py): the 800 x 800 hit mask and depth of the
+reference tracer, and the shading half of the path on the reference's own hit points (tracer out of the loop) at
+north_star's tolerance, adjudicated by the fp64 run of the reference where fp32 round-off exceeds it."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from full800_util import TOL, elem_err, judge, print_report, full_materials
+from gpu_util import sdf_net
+
+pytestmark = pytest.mark.gpu
+
+
+def test_trace_800_mask_and_depth_match_reference():
+    """north_star: hit-mask agreement >= 99.99 % over all 640 000 pixels, depth within 1e-4 relative."""
+    from pir_amd.renderer.raytracer import RayTracer, Camera, raytrace_camera
+    d = load_golden("trace_full800.npz")
+    W, H = int(d["W"]), int(d["H"])
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    cam = Camera(W, H, torch.from_numpy(d["K"]).cuda(), torch.from_numpy(d["W2C"]).cuda())
+    tr = RayTracer()
+    res = raytrace_camera(cam, net, tr)
+    tr.check_status()
+    mask = res["convergent_mask"].reshape(-1).cpu().numpy()
+    ref_mask = np.unpackbits(d["mask_bits"])[:W * H].astype(bool)
+    assert int(ref_mask.sum()) == int(d["n_hits"])
+    diff = int((mask != ref_mask).sum())
+    agree = 1.0 - diff / mask.size
+    sub = d["sub_idx"]
+    both = mask[sub] & ref_mask[sub]
+    depth = res["depth"].reshape(-1).cpu().numpy()[sub][both]
+    rel = np.abs(depth - d["sub_depth"][both]) / d["sub_depth"][both]
+    perr = np.abs(res["points"].reshape(-1, 3).cpu().numpy()[sub][both] - d["sub_points"][both]).max()
+    print(f"\n800x800 trace vs reference: {diff} of {mask.size} pixels differ (agreement {agree:.6f}), hits "
+          f"{int(mask.sum())} vs {int(ref_mask.sum())}; depth rel err max {rel.max():.2e} / median {np.median(rel):.2e} "
+          f"over {int(both.sum())} sampled hits; point abs err max {perr:.2e}")
+    assert agree >= 0.9999
+    assert rel.max() <= TOL
+    assert perr <= 3e-4            # 1e-4 relative of the ray length (~3)
+
+
+def _shade_on_fixture_points(d, net, mats, dino):
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer.raytracer import Camera, light_visibility, render_normal_and_color
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    t = load_golden("trace_full800.npz")
+    dev = next(net.parameters()).device
+    cam = Camera(int(t["W"]), int(t["H"]), torch.from_numpy(t["K"]).to(dev), torch.from_numpy(t["W2C"]).to(dev))
+    pl = mats["point_light_network"]
+    P = d["points"].shape[0]
+    pts = torch.from_numpy(d["points"]).to(dev)
+    results = {"convergent_mask": torch.ones(P, dtype=torch.bool, device=dev), "points": pts.clone(),
+               "ray_d": torch.from_numpy(d["ray_d"]).to(dev), "ray_o": torch.from_numpy(d["ray_o"]).to(dev),
+               "edge_mask": torch.zeros(P, dtype=torch.bool, device=dev)}
+    light_pos = cam.get_light_pos(pl.offset)
+    inv_s = torch.full((1, 1), float(d["inv_s"]), device=dev)
+    vis = light_visibility(light_pos, pts.clone(), net, inv_s, n_samples=128, is_training=True)
+    render_normal_and_color(results, net, mats, dino, make_render_fn(GGXColocatedRenderer(use_cuda=dev.type == "cuda")),
+                            is_training=True, max_num_pts=320000, light_pos=light_pos)
+    cw = torch.from_numpy(d["cw"]).to(dev)
+    loss = (results["color"] * vis[..., None] * cw).sum() + ((results["normal"].norm(dim=-1) - 1.0) ** 2).sum()
+    loss.backward()
+    return results, vis, loss
+
+
+def test_shading_on_reference_hit_points_within_1e4():
+    """get_all + reparam_points + render_fn (full-size material MLPs) + GGX + light_visibility(128) on 2048 hit points
+    of the reference's 800 x 800 trace: every output and every parameter gradient element-wise within 1e-4 of the fp32
+    reference, or no farther from the reference's fp64 run than 2 x the fp32 reference itself is."""
+    d = load_golden("shade_points.npz")
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    mats, dino = full_materials("cuda")
+    results, vis, loss = _shade_on_fixture_points(d, net, mats, dino)
+    report, ok = [], True
+    np_ = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    outs = {"vis": vis, "color": results["color"], "normal": results["normal"],
+            "diffuse_albedo": results["diffuse_albedo"], "specular_albedo": results["specular_albedo"],
+            "specular_roughness": results["specular_roughness"]}
+    for k, v in outs.items():
+        ok &= judge(k, np_(v), d[f"ref32.{k}"], d[f"ref64.{k}"], report)
+    ok &= judge("loss", loss.item(), d["ref32.loss"], d["ref64.loss"], report)
+    pl = mats["point_light_network"]
+    ok &= judge("g_light", np_(pl.light.grad), d["ref32.g_light"], d["ref64.g_light"], report)
+    ok &= judge("g_offset", np_(pl.light_offset.weight.grad), d["ref32.g_offset"], d["ref64.g_offset"], report)
+
+    def sub(g, ref):
+        return g if g.shape == ref.shape else g[::8]
+    for k, p in net.named_parameters():
+        ref = d[f"ref32.g.sdf.{k}"]
+        ok &= judge(f"g.sdf.{k}", sub(np_(p.grad), ref), ref, d[f"ref64.g.sdf.{k}"], report)
+    for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
+        for k, p in mats[nm].named_parameters():
+            ref = d[f"ref32.g.{nm}.{k}"]
+            g = np_(p.grad) if p.grad is not None else np.zeros(p.shape, np.float32)
+            ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report)
+    print_report(report, "shading on the reference's hit points (HIP)")
+    n_direct = sum(1 for r in report if r[4] == "ok")
+    print(f"  {n_direct} of {len(report)} tensors within {TOL:g} of the fp32 reference directly")
+    assert ok, [r for r in report if r[4] == "FAIL"]
+
+
+def test_sdf_backward_vs_fp64_oracle():
+    """SDF get_all backward (value, feature and normal paths) on the sdf_full fixture: the HIP gradients are no farther
+    from an fp64 evaluation (oracle in double) than the reference's own fp32 gradients are."""
+    from oracle import pir_oracle as O
+    from conftest import state_from_npz
+    from gpu_util import grad_np
+    d = load_golden("sdf_full.npz")
+    net = sdf_net("sdf_full.npz")
+    x = torch.from_numpy(d["x"]).cuda().requires_grad_(True)
+    y, f, n = net.get_all(x, is_training=True)
+    ((y * torch.from_numpy(d["cs"]).cuda()).sum() + (n * torch.from_numpy(d["cn"]).cuda()).sum()
+     + (f * torch.from_numpy(d["cf"]).cuda()).sum()).backward()
+    st = {k: v.double().requires_grad_(True) for k, v in state_from_npz(d).items()}
+    x64 = torch.from_numpy(d["x"]).double().requires_grad_(True)
+    y64, f64, n64 = O.sdf_get_all(O.mlp_layers(st), x64, is_training=True)
+    ((y64 * torch.from_numpy(d["cs"]).double()).sum() + (n64 * torch.from_numpy(d["cn"]).double()).sum()
+     + (f64 * torch.from_numpy(d["cf"]).double()).sum()).backward()
+    report, ok = [], True
+    ok &= judge("grad_x", x.grad.cpu().numpy(), d["grad_x"], x64.grad.numpy(), report)
+    for k, p in net.named_parameters():
+        ref = d["g." + k]
+        g64 = st[k].grad.numpy()
+        g64 = g64 if g64.shape == ref.shape else g64[::8]
+        ok &= judge("g." + k, grad_np(p, ref.shape), ref, g64, report)
+    print_report(report, "SDF get_all backward (HIP) vs reference fp32 fixture and fp64 oracle")
+    assert ok, [r for r in report if r[4] == "FAIL"]

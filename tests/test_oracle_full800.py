@@ -1,0 +1,79 @@
+"""CPU: the oracle against the full-size reference fixtures of tools/gen_golden_full800.py (no GPU needed)."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import ROOT, load_golden, state_from_npz
+from full800_util import TOL, judge, print_report, full_materials
+from oracle import pir_oracle as O
+
+
+def test_oracle_trace_subsample_of_800_view():
+    """4000 rays of the 800 x 800 reference trace (rays are independent): mask and depth."""
+    d = load_golden("trace_full800.npz")
+    W = int(d["W"])
+    ref_mask = np.unpackbits(d["mask_bits"])[:W * W].astype(bool)
+    sub = d["sub_idx"][::12][:4000]
+    keep = np.arange(0, d["sub_idx"].shape[0], 12)[:4000]
+    cam = O.CameraRays(W, W, torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"]))
+    uv = torch.stack([torch.from_numpy((sub % W).astype(np.float32)), torch.from_numpy((sub // W).astype(np.float32))], -1) + 0.5
+    o, dd, nrm = cam.rays(uv)
+    layers = O.mlp_layers(state_from_npz(load_golden("sdf_full_bumpy_weights.npz")))
+    hit, lo, hi = O.intersect_sphere(o, dd, 1.0)
+    with torch.no_grad():
+        r = O.Tracer().trace(lambda x: O.sdf_forward(layers, x)[..., 0], o, dd, lo, hi, hit)
+    m = r["convergent_mask"].numpy()
+    assert (m != ref_mask[sub]).sum() <= 1
+    both = m & ref_mask[sub]
+    depth = (r["distance"] / nrm).numpy()[both]
+    rel = np.abs(depth - d["sub_depth"][keep][both]) / d["sub_depth"][keep][both]
+    print("oracle depth rel err on the 800x800 subsample:", rel.max())
+    assert rel.max() <= TOL
+
+
+def test_oracle_shading_on_reference_hit_points():
+    d = load_golden("shade_points.npz")
+    t = load_golden("trace_full800.npz")
+    sdf_state = {k: v.clone().requires_grad_(True) for k, v in state_from_npz(load_golden("sdf_full_bumpy_weights.npz")).items()}
+    mats, dino = full_materials("cpu")
+    from pir_amd import scene
+    mstates = {k: {n: p.detach().clone().requires_grad_(True) for n, p in mats[k].state_dict().items()}
+               for k in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network")}
+    omats = {k: dict(layers=O.mlp_layers(st), cfg=scene.MODEL_CONFIG[k]) for k, st in mstates.items()}
+    odino = dict(layers=O.mlp_layers(dict(dino.state_dict())), cfg=scene.MODEL_CONFIG["dino_network"])
+    tables = O.load_ggx_tables(os.path.join(ROOT, "pir_amd", "renderer", "ggx"))
+    cam = O.CameraRays(int(t["W"]), int(t["H"]), torch.from_numpy(t["K"]), torch.from_numpy(t["W2C"]))
+    light = torch.tensor(135.0, requires_grad=True)
+    off = torch.tensor([[0.2, 0.1, 0.0]], requires_grad=True)
+    light_pos = cam.light_pos(off)
+    pts, ray_d, ray_o = (torch.from_numpy(d[k]) for k in ("points", "ray_d", "ray_o"))
+    layers = O.mlp_layers(sdf_state)
+    inv_s = torch.full((1, 1), float(d["inv_s"]))
+    vis = O.light_visibility(light_pos, pts, layers, inv_s, n_samples=128, is_training=True)
+    sdf, feat, nrm = O.sdf_get_all(layers, pts, is_training=True)
+    dino_f = O.dino_mlp(odino["layers"], odino["cfg"], pts).detach()
+    p = O.reparam_points(pts, nrm.detach(), -ray_d, sdf)
+    lightdir = torch.nn.functional.normalize(p - light_pos, eps=1e-10)
+    distance = (p - light_pos).norm(dim=-1, keepdim=True)
+    mask = torch.ones(pts.shape[0], dtype=torch.bool)
+    out = O.render_fn(mask, omats, tables, ray_o, ray_d, p, nrm, feat, dino_f, light, lightdir, distance)
+    loss = (out["color"] * vis[..., None] * torch.from_numpy(d["cw"])).sum() + ((out["normal"].norm(dim=-1) - 1.0) ** 2).sum()
+    loss.backward()
+    report, ok = [], True
+    for k, v in (("vis", vis), ("color", out["color"]), ("normal", out["normal"]),
+                 ("diffuse_albedo", out["diffuse_albedo"]), ("specular_roughness", out["specular_roughness"])):
+        ok &= judge(k, v.detach().numpy(), d[f"ref32.{k}"], d[f"ref64.{k}"], report)
+    ok &= judge("g_light", light.grad.numpy(), d["ref32.g_light"], d["ref64.g_light"], report)
+    ok &= judge("g_offset", off.grad.numpy(), d["ref32.g_offset"], d["ref64.g_offset"], report)
+    sub = lambda g, ref: g if g.shape == ref.shape else g[::8]  # noqa: E731
+    for k, v in sdf_state.items():
+        ref = d[f"ref32.g.sdf.{k}"]
+        ok &= judge(f"g.sdf.{k}", sub(v.grad.numpy(), ref), ref, d[f"ref64.g.sdf.{k}"], report)
+    for nm, st in mstates.items():
+        for k, v in st.items():
+            ref = d[f"ref32.g.{nm}.{k}"]
+            g = v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)
+            ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report)
+    print_report(report, "shading on the reference's hit points (oracle, CPU fp32)")
+    assert ok, [r for r in report if r[4] == "FAIL"]
