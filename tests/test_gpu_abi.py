@@ -22,9 +22,9 @@ def test_camera_rays_abi_matches_reference(mode):
     d = load_golden("camera.npz")
     W, H = int(d["W"]), int(d["H"])
     n = W * H
-    K, W2C = torch.from_numpy(d["K"]).double(), torch.from_numpy(d["W2C"]).double()
-    K_inv, C2W = torch.inverse(K), torch.inverse(W2C)
-    cam21 = torch.cat([K_inv[:3, :3].reshape(-1), C2W[:3, :3].reshape(-1), C2W[:3, 3].reshape(-1)]).float().cuda()
+    from pir_amd.renderer.raytracer import Camera
+    # K_inv / C2W as the reference forms them: fp32 torch.inverse on the host (raytracer.py:277-289)
+    cam21 = Camera(W, H, torch.from_numpy(d["K"]), torch.from_numpy(d["W2C"])).cam21().cuda()
     uv = torch.from_numpy(d["uv"]).reshape(-1, 2).contiguous().cuda()
     o, dd = torch.empty(n, 3, device="cuda"), torch.empty(n, 3, device="cuda")
     nrm, lo, hi = torch.empty(n, device="cuda"), torch.empty(n, device="cuda"), torch.empty(n, device="cuda")

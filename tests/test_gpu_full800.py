@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from full800_util import TOL, elem_err, judge, print_report, full_materials
+from full800_util import TOL, judge, verdicts, print_report, full_materials
 from gpu_util import sdf_net
 
 pytestmark = pytest.mark.gpu
@@ -94,6 +94,7 @@ def test_shading_on_reference_hit_points_within_1e4():
             ref = d[f"ref32.g.{nm}.{k}"]
             g = np_(p.grad) if p.grad is not None else np.zeros(p.shape, np.float32)
             ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report)
+    ok = verdicts(report)
     print_report(report, "shading on the reference's hit points (HIP)")
     n_direct = sum(1 for r in report if r[4] == "ok")
     print(f"  {n_direct} of {len(report)} tensors within {TOL:g} of the fp32 reference directly")
@@ -124,5 +125,6 @@ def test_sdf_backward_vs_fp64_oracle():
         g64 = st[k].grad.numpy()
         g64 = g64 if g64.shape == ref.shape else g64[::8]
         ok &= judge("g." + k, grad_np(p, ref.shape), ref, g64, report)
+    ok = verdicts(report)
     print_report(report, "SDF get_all backward (HIP) vs reference fp32 fixture and fp64 oracle")
     assert ok, [r for r in report if r[4] == "FAIL"]

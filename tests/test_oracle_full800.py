@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from conftest import ROOT, load_golden, state_from_npz
-from full800_util import TOL, judge, print_report, full_materials
+from full800_util import TOL, judge, verdicts, print_report, full_materials
 from oracle import pir_oracle as O
 
 
@@ -75,5 +75,6 @@ def test_oracle_shading_on_reference_hit_points():
             ref = d[f"ref32.g.{nm}.{k}"]
             g = v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)
             ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report)
+    ok = verdicts(report)
     print_report(report, "shading on the reference's hit points (oracle, CPU fp32)")
     assert ok, [r for r in report if r[4] == "FAIL"]
