@@ -26,15 +26,19 @@ FWD_FLOP_SDF = 918016       # SDF forward, sdf output only
 PEAK_F32_MFMA = 157.3       # TFLOP/s, MI355X_MICROARCH.md chip table
 
 
-def build_step(res, rank, world, device):
+def build_step(res, rank, world, device, shard="views"):
     from pir_amd import scene
-    from pir_amd.parallel import FlatGradBucket
+    from pir_amd.parallel import FlatGradBucket, render_camera_rows, shard_rows
     from pir_amd.render_fn import make_render_fn
     from pir_amd.renderer.raytracer import RayTracer, render_camera
     from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
 
     sdf, mats, dino = scene.build_networks(seed=0, device=device)
-    cam = scene.make_camera(res, res, view=rank, n_views=world, device=device)
+    # shard == "views": one view per rank (weak scaling, BASELINE config 4); "rows": all ranks share view 0 and render
+    # interleaved rows of it (strong scaling of one image)
+    cam = scene.make_camera(res, res, view=rank if shard == "views" else 0, n_views=world if shard == "views" else 1,
+                            device=device)
+    rows = shard_rows(res, rank, world) if shard == "rows" else None
     tracer = RayTracer()
     render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
     inv_s = torch.full((1, 1), scene.INV_S, device=device)
@@ -57,13 +61,17 @@ def build_step(res, rank, world, device):
         for o in opts:
             o.zero_grad(set_to_none=True)
         light_pos = cam.get_light_pos(pl.offset)
-        results = render_camera(cam, sdf, tracer, mats, dino, render_fn, fill_holes=False, handle_edges=False,
-                                inv_s=inv_s, render_visibility=True, max_num_pts=512, light_pos=light_pos,
-                                indirect_warmup=True, is_training=True)
+        if rows is None:
+            results = render_camera(cam, sdf, tracer, mats, dino, render_fn, fill_holes=False, handle_edges=False,
+                                    inv_s=inv_s, render_visibility=True, max_num_pts=512, light_pos=light_pos,
+                                    indirect_warmup=True, is_training=True)
+        else:
+            results = render_camera_rows(cam, rows, sdf, tracer, mats, dino, render_fn, inv_s=inv_s,
+                                         render_visibility=True, light_pos=light_pos, is_training=True)
         loss = scene.step_loss(results)
         loss.backward()
         if bucket is not None:
-            bucket.all_reduce()
+            bucket.all_reduce(average=False)     # sum loss over all rays of all ranks
         for o in opts:
             o.step()
         with torch.no_grad():
@@ -169,6 +177,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a rehearsal "
                                                       "of the multi-process path with every rank on one GPU)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--shard", choices=["views", "rows"], default="views",
+                    help="views: one res x res view per GPU (weak scaling, the default the driver measures); rows: the "
+                         "ranks split the rows of ONE view (strong scaling)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,7 +199,7 @@ def main():
 
     from pir_amd import _lib
     L = _lib.lib()
-    step, info, nets = build_step(args.res, rank, world, device)
+    step, info, nets = build_step(args.res, rank, world, device, args.shard)
 
     def barrier():
         if world > 1:
@@ -258,19 +269,21 @@ def main():
     nz = sdf_autograd.stats.get("last_nonzero_fraction")
 
     if rank == 0:
-        rays = args.res * args.res * world * args.steps
+        views = world if args.shard == "views" else 1
+        rays = args.res * args.res * views * args.steps
         out = {"metric": "rays/sec fwd+bwd (trace+GGX+shadow) at 800x800", "value": round(rays / dt, 1),
                "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak" if args.shard == "views" else "strong",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{args.res}x{args.res} view per GPU: sphere trace + light-visibility march "
                                       "(128 samples) + GGX shade, fwd+bwd + Adam step, random-init nets "
                                       "(configs/model_config.json), offset point light",
-                          "views": world, "hits_per_view": hits, "scene": "frozen (parameters restored after "
+                          "views": views, "hits_per_view" if args.shard == "views" else "hits_rank0": hits, "scene": "frozen (parameters restored after "
                           "every Adam step; hit mask identical at the first and the last step)",
                           "march_samples_per_view": hits * 118,
                           "backward_march_samples_per_view": None if nz is None else int(round(nz * hits * 118)),
-                          "parallelism": f"dp{world} (one view per GPU, flat RCCL grad all-reduce)"},
+                          "parallelism": (f"dp{world} (one view per GPU, flat RCCL grad all-reduce)" if args.shard == "views"
+                                          else f"dp{world} (interleaved rows of one view per GPU, flat RCCL grad all-reduce)")},
                "roofline": roofline, "kernels": breakdown}
         if world == 1 and not args.no_cpu_baseline:
             torch.cuda.empty_cache()

@@ -1,0 +1,179 @@
+"""GPU coverage of BASELINE configs 4 and 5: multi-light relighting at 2048 x 2048 (properties + oracle subsample),
+row-sharded rendering of one view on one device, and the 2-process data-parallel step (gloo rehearsal on cuda:0)."""
+import json
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, state_from_npz
+from gpu_util import sdf_net
+
+pytestmark = pytest.mark.gpu
+
+
+def fibonacci_lights(n, radius=3.0, device="cuda"):
+    out = []
+    for i in range(n):
+        z = 1 - 2 * (i + 0.5) / n
+        r = math.sqrt(1 - z * z)
+        a = math.pi * (1 + 5 ** 0.5) * i
+        out.append(torch.tensor([[radius * r * math.cos(a), radius * r * math.sin(a), radius * z]], device=device))
+    return out
+
+
+def test_config5_trace_2048_properties_and_oracle_subsample():
+    """2048 x 2048 trace (4.2 M rays, 21 chunks of 200 000): determinism, geometric consistency, hit fraction equal to
+    the 800 x 800 view's (same focal/size ratio), and 1200 rays re-traced by the CPU oracle."""
+    from oracle import pir_oracle as O
+    from pir_amd import scene
+    from pir_amd.renderer.raytracer import RayTracer, raytrace_camera
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    cam = scene.make_camera(2048, 2048, device="cuda")
+    tr = RayTracer()
+    res = raytrace_camera(cam, net, tr)
+    res2 = raytrace_camera(cam, net, tr)
+    tr.check_status()
+    for k in ("convergent_mask", "points", "distance"):
+        assert torch.equal(res[k], res2[k]), k
+    m = res["convergent_mask"]
+    frac = m.float().mean().item()
+    ref800 = int(load_golden("trace_full800.npz")["n_hits"]) / 640000.0
+    assert abs(frac - ref800) < 2e-3, (frac, ref800)
+    pts, dist = res["points"][m], res["distance"][m]
+    assert (pts - (res["ray_o"][m] + res["ray_d"][m] * dist[:, None])).abs().max().item() < 2e-5
+    assert (net.sdf(pts)[:, 0].abs() < 2e-3).all()
+    g = torch.Generator().manual_seed(7)
+    idx = torch.randperm(2048 * 2048, generator=g)[:1200].cuda()
+    layers = O.mlp_layers(state_from_npz(load_golden("sdf_full_bumpy_weights.npz")))
+    o, dd = res["ray_o"].reshape(-1, 3)[idx].cpu(), res["ray_d"].reshape(-1, 3)[idx].cpu()
+    hit, lo, hi = O.intersect_sphere(o, dd, 1.0)
+    ref = O.Tracer().trace(lambda x: O.sdf_forward(layers, x)[..., 0], o, dd, lo, hi, hit)
+    got_m = m.reshape(-1)[idx].cpu()
+    assert (got_m != ref["convergent_mask"]).sum().item() <= 1
+    both = got_m & ref["convergent_mask"]
+    rel = ((res["distance"].reshape(-1)[idx].cpu() - ref["distance"])[both].abs() / ref["distance"][both]).max().item()
+    print("2048x2048 trace: hit fraction", frac, "distance rel err vs oracle", rel)
+    assert rel <= 1e-4
+
+
+def test_config5_multilight_16_vs_oracle_subsample():
+    """16 lights on a Fibonacci sphere: visibility(128) + GGX shade (forward) of the hit points of a 256 x 256 view on
+    the GPU; for every light 24 hit points are re-marched and re-shaded by the CPU oracle."""
+    from oracle import pir_oracle as O
+    from pir_amd import scene
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer.raytracer import (RayTracer, raytrace_camera, render_light_visibility,
+                                            render_normal_and_color)
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    sdf, mats, dino = scene.build_networks(seed=0, device="cuda")
+    cam = scene.make_camera(256, 256, device="cuda")
+    inv_s = torch.full((1, 1), scene.INV_S, device="cuda")
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    cpu = lambda mod: {k: v.detach().cpu() for k, v in mod.state_dict().items()}  # noqa: E731
+    layers = O.mlp_layers(cpu(sdf))
+    omats = {k: dict(layers=O.mlp_layers(cpu(mats[k])), cfg=scene.MODEL_CONFIG[k])
+             for k in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network")}
+    odino = dict(layers=O.mlp_layers(cpu(dino)), cfg=scene.MODEL_CONFIG["dino_network"])
+    tables = O.load_ggx_tables(os.path.join(ROOT, "pir_amd", "renderer", "ggx"))
+    light = torch.tensor(scene.LIGHT_INTENSITY)
+    worst_v = worst_c = 0.0
+    with torch.no_grad():
+        res = raytrace_camera(cam, sdf, RayTracer())
+        m = res["convergent_mask"].reshape(-1)
+        hits = m.nonzero()[:, 0]
+        g = torch.Generator().manual_seed(16)
+        lit_any = torch.zeros_like(m)
+        for li, lp in enumerate(fibonacci_lights(16)):
+            render_light_visibility(res, cam, lp, sdf, inv_s, n_samples=128, is_training=False)
+            render_normal_and_color(res, sdf, mats, dino, render_fn, is_training=False, light_pos=lp)
+            vis, color = res["vis"].reshape(-1), res["color"].reshape(-1, 3)
+            assert float(vis.min()) >= 0.0 and float(vis.max()) <= 1.0 + 1e-5
+            lit_any |= vis > 0.5
+            idx = hits[torch.randperm(hits.numel(), generator=g)[:24].cuda()]
+            pts = res["points"].reshape(-1, 3)[idx].cpu()
+            ray_d, ray_o = res["ray_d"].reshape(-1, 3)[idx].cpu(), res["ray_o"].reshape(-1, 3)[idx].cpu()
+            lpc = lp.cpu()
+            v_ref = O.light_visibility(lpc, pts, layers, inv_s.cpu(), n_samples=128, is_training=False)
+            _, feat, nrm = O.sdf_get_all(layers, pts, is_training=False)
+            dino_f = O.dino_mlp(odino["layers"], odino["cfg"], pts)
+            lightdir = torch.nn.functional.normalize(pts - lpc, eps=1e-10)
+            distance = (pts - lpc).norm(dim=-1, keepdim=True)
+            out = O.render_fn(torch.ones(24, dtype=torch.bool), omats, tables, ray_o, ray_d, pts, nrm, feat, dino_f,
+                              light, lightdir, distance)
+            ev = (vis[idx].cpu() - v_ref).abs().max().item()
+            ec = ((color[idx].cpu() - out["color"]).abs() / (out["color"].abs() + out["color"].abs().mean() + 1e-12)).max().item()
+            worst_v, worst_c = max(worst_v, ev), max(worst_c, ec)
+        # lights all around the object: (nearly) every hit point is lit by at least one of them
+        assert lit_any[m].float().mean().item() > 0.95
+    print("16 lights: worst |vis - oracle|", worst_v, "worst colour element-relative err", worst_c)
+    assert worst_v < 1e-4 and worst_c < 1e-4
+
+
+def test_row_sharded_render_equals_full_render_on_one_device():
+    """render_camera_rows over 3 interleaved row sets == render_camera of the whole view (images and summed
+    gradients): the single-device rehearsal of strong scaling."""
+    from pir_amd import scene
+    from pir_amd.parallel import render_camera_rows, shard_rows, gather_rows
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer.raytracer import RayTracer, render_camera
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    H = W = 96
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    inv_s = torch.full((1, 1), scene.INV_S, device="cuda")
+
+    def nets():
+        sdf, mats, dino = scene.build_networks(seed=0, device="cuda")
+        params = [p for mod in [sdf] + [mats[k] for k in sorted(mats)] for p in mod.parameters()]
+        return sdf, mats, dino, params
+    sdf, mats, dino, params = nets()
+    cam = scene.make_camera(W, H, device="cuda")
+    lp = cam.get_light_pos(mats["point_light_network"].offset)
+    full = render_camera(cam, sdf, RayTracer(), mats, dino, render_fn, fill_holes=False, handle_edges=False, inv_s=inv_s,
+                         render_visibility=True, light_pos=lp, indirect_warmup=True, is_training=True)
+    scene.step_loss(full).backward()
+    sdf2, mats2, dino2, params2 = nets()
+    world, parts, rows_all = 3, {"color": [], "vis": [], "convergent_mask": []}, []
+    for r in range(world):
+        rows = shard_rows(H, r, world)
+        lp2 = cam.get_light_pos(mats2["point_light_network"].offset)
+        out = render_camera_rows(cam, rows, sdf2, RayTracer(), mats2, dino2, render_fn, inv_s=inv_s,
+                                 render_visibility=True, light_pos=lp2, is_training=True)
+        scene.step_loss(out).backward()           # gradients accumulate over the "ranks" = the all-reduce SUM
+        rows_all.append(rows)
+        for k in parts:
+            parts[k].append(out[k].detach())
+    assert torch.equal(gather_rows(parts["convergent_mask"], H, rows_all), full["convergent_mask"])
+    for k in ("color", "vis"):
+        a, b = gather_rows(parts[k], H, rows_all), full[k].detach()
+        err = ((a - b).abs() / (b.abs() + b.abs().mean())).max().item()
+        assert err < 1e-4, (k, err)
+    worst = 0.0
+    for p, q in zip(params2, params):
+        if q.grad is None:
+            assert p.grad is None
+            continue
+        worst = max(worst, ((p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)).item())
+    print("row-sharded vs full render: worst max-normalised gradient difference", worst)
+    assert worst < 2e-4
+
+
+def test_bench_two_ranks_one_device_rehearsal():
+    """bench.py under torch.distributed.run with 2 ranks (gloo, both on cuda:0), view- and row-sharded: the
+    multi-process path of BASELINE config 4 end to end on tiny views; strong-scaling mode reports one view."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for shard, port in (("views", "29551"), ("rows", "29552")):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+               "--warmup", "1", "--res", "64", "--backend", "gloo", "--one-device", "--shard", shard]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=280)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and out["value"] > 0
+        assert out["scaling"] == ("weak" if shard == "views" else "strong")
+        assert out["config"]["views"] == (2 if shard == "views" else 1)

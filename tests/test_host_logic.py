@@ -152,6 +152,101 @@ def test_data_parallel_grad_bucket_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+_DP_RENDER_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+from pir_amd import scene
+from pir_amd.parallel import FlatGradBucket, render_camera_rows, shard_rows
+from pir_amd.render_fn import make_render_fn
+from pir_amd.renderer.raytracer import RayTracer, render_camera
+from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.set_num_threads(2)
+H = W = 12
+
+
+def run(rows):
+    sdf, mats, dino = scene.build_networks(seed=0)
+    cam = scene.make_camera(W, H)
+    pl = mats["point_light_network"]
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=False))
+    inv_s = torch.full((1, 1), scene.INV_S)
+    light_pos = cam.get_light_pos(pl.offset)
+    if rows is None:
+        r = render_camera(cam, sdf, RayTracer(), mats, dino, render_fn, fill_holes=False, handle_edges=False,
+                          inv_s=inv_s, render_visibility=True, light_pos=light_pos, indirect_warmup=True,
+                          is_training=True)
+    else:
+        r = render_camera_rows(cam, rows, sdf, RayTracer(), mats, dino, render_fn, inv_s=inv_s,
+                               render_visibility=True, light_pos=light_pos, is_training=True)
+    scene.step_loss(r).backward()
+    params = [p for m in [sdf] + [mats[k] for k in sorted(mats)] for p in m.parameters()]
+    return r, params, mats
+
+
+rows = shard_rows(H, rank, world)
+r, params, mats = run(rows)
+bucket = FlatGradBucket(params)
+bucket.all_reduce(average=False)
+full, ref_params, _ = run(None)
+# (1) the rows this rank rendered are the same rows of the single-process image
+for k in ("color", "vis", "normal", "depth"):
+    a, b = r[k].detach(), full[k].detach()[rows]
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (k, (a - b).abs().max())
+assert torch.equal(r["convergent_mask"], full["convergent_mask"][rows])
+assert int(full["convergent_mask"].sum()) > 30 and int(r["convergent_mask"].sum()) > 10
+# (2) the all-reduced (summed) gradients are the single-process gradients
+n_none = 0
+for p, q in zip(params, ref_params):
+    if q.grad is None:
+        assert p.grad is None        # e.g. blend_network: not in the graph on any rank -> stays None (Adam skips it)
+        n_none += 1
+        continue
+    err = (p.grad - q.grad).abs().max() / (q.grad.abs().max() + 1e-30)
+    assert err < 2e-4, err
+assert n_none > 0
+opt = torch.optim.Adam(mats["blend_network"].parameters(), lr=1e-3)
+opt.step()
+assert len(opt.state) == 0           # no state initialised, no step counted for parameters without a gradient
+# (3) a parameter that only one rank differentiates gets that rank's gradient everywhere
+q = torch.nn.Parameter(torch.ones(3))
+if rank == 0:
+    (q * torch.tensor([1.0, 2.0, 3.0])).sum().backward()
+FlatGradBucket([q]).all_reduce(average=False)
+assert q.grad is not None and torch.equal(q.grad, torch.tensor([1.0, 2.0, 3.0]))
+dist.destroy_process_group()
+print("ok", rank)
+"""
+
+
+def test_render_path_row_sharding_gloo_world2(tmp_path):
+    """Two ranks render interleaved rows of one view (trace + visibility + shade, fwd + bwd) and all-reduce their
+    gradients: images and gradients equal the single-process render; parameters outside the graph keep grad=None."""
+    script = tmp_path / "dp_render_worker.py"
+    script.write_text(_DP_RENDER_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
+def test_shard_units_cover_views_and_rows():
+    from pir_amd.parallel import shard_units, shard_rows
+    for n_views, world in ((8, 8), (16, 8), (1, 8), (2, 8), (3, 2), (1, 1)):
+        units = [u for r in range(world) for u in shard_units(n_views, 4, r, world)]
+        cover = {}
+        for v, rr, rw in units:
+            cover.setdefault(v, []).extend(shard_rows(32, rr, rw).tolist())
+        assert sorted(cover) == list(range(n_views)), (n_views, world)
+        assert all(sorted(rows) == list(range(32)) for rows in cover.values()), (n_views, world)
+
+
 def test_image_losses_match_reference():
     from pir_amd.models.image_losses import PyramidL2Loss, ssim_loss_fn
     d = load_golden("image_losses.npz")
