@@ -135,6 +135,24 @@ int pir_ggx_backward(long P, const float* light, int light_is_rgb, int direct_ra
                      float* g_normal, float* g_lightdir, float* g_viewdir, float* g_kd, float* g_ks, float* g_alpha,
                      void* stream);
 
+/* ---- shading inputs (src/renderer/raytracer.py:18-25 reparam_points, :830-833 lightdir / distance;
+ *      render_surface.py:121 normal normalisation, :134-135 collocated distance) ---------------------------- */
+
+/* n_hat [P,3] = normal / (|normal| + 1e-10); distance [P] = |points - origin|; lightdir [P,3] (NULL to skip) =
+ * (points - origin) / max(|points - origin|, 1e-10).  origin: light_pos (3 floats) or, with origin_per_point, ray_o
+ * [P,3] (the collocated light).  The re-parameterised point of reparam_points equals `points` in value. */
+int pir_shade_inputs_forward(long P, const float* points, const float* normal, const float* origin,
+                             int origin_per_point, float* nhat, float* lightdir, float* distance, void* stream);
+/* Backward of the above together with reparam_points: g_points [P,3] (NULL = zero) is the gradient reaching the
+ * re-parameterised point from its other consumers (the material MLPs).  Writes g_normal [P,3] (from n_hat only: the
+ * reference detaches the normal inside reparam_points), g_sdf [P] = -((g_points + g_p(lightdir, distance)) . dir) /
+ * clamp(normal . dir, 1e-4) with dir = -ray_d (NULL: no re-parameterisation, is_training=False), and g_origin [P,3]
+ * per-point contributions to d L / d light_pos (NULL to skip; sum them). */
+int pir_shade_inputs_backward(long P, const float* points, const float* normal, const float* ray_d, const float* origin,
+                              int origin_per_point, const float* g_nhat, const float* g_lightdir,
+                              const float* g_distance, const float* g_points, float* g_normal, float* g_sdf,
+                              float* g_origin, void* stream);
+
 /* ---- material / feature-field MLPs (src/network.py:146-267 RenderingNetwork, :382-467 DINONetwork, :295-367
  *      BlendNetwork): ReLU MLPs with 256-wide hidden layers, the input optionally concatenated again at one skip
  *      layer ([h | x] / sqrt 2, :237-238), linear output layer ------------------------------------------------ */

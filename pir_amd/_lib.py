@@ -70,6 +70,10 @@ def _declare(L):
     L.pir_visibility_forward.argtypes = [vp, vp, vp, vp, vp, lg, i32, vp, vp]
     L.pir_visibility_backward.restype = i32
     L.pir_visibility_backward.argtypes = [vp, vp, vp, vp, vp, vp, lg, i32, vp, vp, vp, vp, vp]
+    L.pir_shade_inputs_forward.restype = i32
+    L.pir_shade_inputs_forward.argtypes = [lg, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.pir_shade_inputs_backward.restype = i32
+    L.pir_shade_inputs_backward.argtypes = [lg, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pir_mlp_product_floats.restype = sz
     L.pir_mlp_product_floats.argtypes = [i32]
     L.pir_mlp_pack_product.restype = i32
@@ -111,3 +115,12 @@ def ptr(t):
 
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def stream_key(device):
+    """(device index, current stream handle): scratch / workspace caches are keyed by it, so that work enqueued on
+    different streams of one GPU never shares a scratch buffer (kernels on one stream are ordered, across streams
+    they are not)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return idx, int(torch.cuda.current_stream(idx).cuda_stream)

@@ -269,14 +269,15 @@ class eager_grad:
 
 
 def _backward_scratch(device, n_hidden):
-    key = (torch.device(device).index, n_hidden)
+    skey = _lib.stream_key(device)
+    key = skey + (n_hidden,)
     buf = _bwd_scratch_cache.get(key)
     if buf is None:
         # the SDF backward's buffer is larger than any material network needs: share it when it exists
         from . import sdf_hip
         need = _lib.lib().pir_mlp_backward_scratch_bytes(n_hidden, BWD_CHUNK_POINTS)
-        for (idx, _), b in sdf_hip._bwd_scratch_cache.items():
-            if idx == torch.device(device).index and b.numel() >= need:
+        for k, b in sdf_hip._bwd_scratch_cache.items():
+            if k[:2] == skey and b.numel() >= need:      # same device AND same stream only
                 buf = b
                 break
         if buf is None:

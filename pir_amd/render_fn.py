@@ -44,7 +44,11 @@ def make_render_fn(ggx_renderer, is_metal=False, smoothness_weight=0.0):
         any_hit = bool(interior_mask.any())
         if any_hit:
             idx = interior_mask.nonzero(as_tuple=True)
-            normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
+            from .shade_hip import UnitNormals
+            if isinstance(normals, UnitNormals):   # already n / (|n| + 1e-10), from the fused shading-input kernel
+                normals = normals.as_subclass(torch.Tensor)
+            else:
+                normals = normals / (normals.norm(dim=-1, keepdim=True) + 1e-10)
             kd, ks, rough, ks_g, rough_g = get_materials(color_network_dict, points, normals, geo_f, dino_f,
                                                          is_training=is_training, roughness_warmup=roughness_warmup)
             if light is None:
@@ -73,4 +77,5 @@ def make_render_fn(ggx_renderer, is_metal=False, smoothness_weight=0.0):
         return out
 
     render_fn.get_materials = get_materials
+    render_fn.accepts_unit_normals = True
     return render_fn

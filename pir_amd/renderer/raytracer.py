@@ -22,6 +22,7 @@ from .. import _lib
 
 VERBOSE_MODE = False
 dimension = 384
+FUSED_SHADE_INPUTS = True   # A/B switch: False = the eager PyTorch expressions of the reference for a9 / shading inputs
 
 
 def reparam_points(nondiff_points, nondiff_grads, nondiff_trgt_dirs, diff_sdf_vals):
@@ -45,7 +46,7 @@ _trace_ws = {}
 
 
 def _workspace(device, nbytes):
-    key = torch.device(device).index
+    key = _lib.stream_key(device)      # one workspace per (device, stream): traces on different streams do not race
     buf = _trace_ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
@@ -148,7 +149,7 @@ class RayTracer(nn.Module):
 
     def trace_status(self, device):
         """Synchronising check that the last native trace on `device` did not hit the bisection bound."""
-        ws = _trace_ws.get(torch.device(device).index)
+        ws = _trace_ws.get(_lib.stream_key(device))
         if ws is None:
             return 0
         st = ctypes.c_int(0)
@@ -530,24 +531,33 @@ def render_normal_and_color(results, sdf_network, color_network_dict, dino_netwo
     dots_sh = list(results["convergent_mask"].shape)
     mask = results["convergent_mask"].reshape(-1)
     empty = torch.zeros(0, dtype=torch.float32, device=mask.device)
+    fused = False
     if mask.any():
         points = results["points"].reshape(-1, 3)[mask]
         ray_d = results["ray_d"].reshape(-1, 3)[mask]
         ray_o = results["ray_o"].reshape(-1, 3)[mask]
         sdf, feature, normal = sdf_network.get_all(points, is_training=is_training)
         dino_feature = dino_network(points, is_training=False)
-        if is_training:
+        fused = points.is_cuda and FUSED_SHADE_INPUTS and getattr(render_fn, "accepts_unit_normals", False)
+        if fused:
+            # reparam_points + normal normalisation + lightdir / distance in one kernel each way (pir_shade_inputs_*)
+            from .. import shade_hip
+            with torch.set_grad_enabled(is_training):
+                points, normal, lightdir, distance = shade_hip.shade_inputs(points, sdf, normal, ray_d, ray_o,
+                                                                            light_pos, is_training)
+        elif is_training:
             points = reparam_points(points, normal.detach(), -ray_d.detach(), sdf)
     else:
         points = ray_d = ray_o = normal = feature = dino_feature = empty
     with torch.set_grad_enabled(is_training):
-        lightdir = distance = None
-        if light_pos is not None:
-            if mask.any():
-                lightdir = F.normalize(points - light_pos, eps=1e-10)
-                distance = (points - light_pos).norm(dim=-1, keepdim=True)
-            else:
-                lightdir = empty
+        if not fused:
+            lightdir = distance = None
+            if light_pos is not None:
+                if mask.any():
+                    lightdir = F.normalize(points - light_pos, eps=1e-10)
+                    distance = (points - light_pos).norm(dim=-1, keepdim=True)
+                else:
+                    lightdir = empty
         render_results = render_fn(mask, color_network_dict, ray_o, ray_d, points, normal, feature,
                                    dino_f=dino_feature, is_training=is_training, lightdir=lightdir, distance=distance,
                                    roughness_warmup=roughness_warmup)

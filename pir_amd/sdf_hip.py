@@ -15,11 +15,11 @@ def supported_architecture(shapes: Sequence[Tuple[int, int]]) -> bool:
 
 
 def scratch_for(device, n_workgroups: Optional[int] = None) -> torch.Tensor:
-    """Per-device scratch for the resident workgroups of the get_all sweeps (2 per CU)."""
+    """Per-(device, stream) scratch for the resident workgroups of the get_all sweeps (2 per CU)."""
     per = _lib.lib().pir_sdf_scratch_bytes_per_workgroup()
     if n_workgroups is None:
         n_workgroups = 2 * torch.cuda.get_device_properties(device).multi_processor_count
-    key = (torch.device(device).index, n_workgroups)
+    key = _lib.stream_key(device) + (n_workgroups,)
     buf = _scratch_cache.get(key)
     if buf is None:
         buf = torch.empty(per * n_workgroups, dtype=torch.uint8, device=device)
@@ -74,7 +74,7 @@ BWD_CHUNK_POINTS = 131072
 
 def backward_scratch_for(device, chunk_points: int = None) -> torch.Tensor:
     chunk_points = chunk_points or BWD_CHUNK_POINTS
-    key = (torch.device(device).index, chunk_points)
+    key = _lib.stream_key(device) + (chunk_points,)
     buf = _bwd_scratch_cache.get(key)
     if buf is None:
         buf = torch.empty(_lib.lib().pir_sdf_backward_scratch_bytes(chunk_points), dtype=torch.uint8, device=device)

@@ -90,3 +90,53 @@ def test_bisection_runs_as_many_rounds_as_the_reference():
     with pytest.raises(RuntimeError, match="bisection bound"):
         tr.check_status()
     tr.check_status()                                 # the flag was reset by the failed check
+
+
+@pytest.mark.parametrize("collocated", [False, True])
+def test_shade_inputs_kernel_matches_torch_expressions(collocated):
+    """pir_shade_inputs_* (reparam_points + normal normalisation + lightdir / distance fused) against the reference's
+    eager expressions (raytracer.py:18-25, :830-833, render_surface.py:121, :134-135): values bit-exact, gradients
+    to sdf, normal and the light position element-wise."""
+    import torch.nn.functional as F
+    from pir_amd import shade_hip
+    from pir_amd.renderer.raytracer import reparam_points
+    g = torch.Generator().manual_seed(13)
+    P = 10_007
+    pts = (F.normalize(torch.randn(P, 3, generator=g), dim=-1) * 0.5).cuda()
+    ray_o = torch.tensor([[0.0, 0.0, -3.0]], device="cuda").repeat(P, 1)
+    ray_d = F.normalize(pts - ray_o, dim=-1)
+    nrm0 = (pts * 2.1 + 0.2 * torch.randn(P, 3, generator=g).cuda())
+    nrm0[:50] = -nrm0[:50]                       # back-facing: the 1e-4 clamp of reparam_points is active
+    sdf0 = 1e-5 * torch.randn(P, 1, generator=g).cuda()
+    w = [torch.randn(P, 3, generator=g).cuda() for _ in range(3)] + [torch.randn(P, 1, generator=g).cuda()]
+    outs = []
+    for fused in (True, False):
+        sdf, nrm = sdf0.clone().requires_grad_(True), nrm0.clone().requires_grad_(True)
+        lp = torch.tensor([[0.2, 0.1, -3.0]], device="cuda", requires_grad=True)
+        if fused:
+            p, nh, ld, dist = shade_hip.shade_inputs(pts, sdf, nrm, ray_d, ray_o, None if collocated else lp, True)
+        else:
+            p = reparam_points(pts, nrm.detach(), -ray_d, sdf)
+            nh = nrm / (nrm.norm(dim=-1, keepdim=True) + 1e-10)
+            org = ray_o if collocated else lp
+            ld = None if collocated else F.normalize(p - org, eps=1e-10)
+            dist = (p - org).norm(dim=-1, keepdim=True)
+        loss = (p * w[0]).sum() + (nh * w[1]).sum() + (dist * w[3]).sum()
+        if ld is not None:
+            loss = loss + (ld * w[2]).sum()
+        loss.backward()
+        outs.append((p.detach(), nh.detach(), None if ld is None else ld.detach(), dist.detach(), sdf.grad, nrm.grad,
+                     lp.grad))
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[0], pts)
+    for i, name in ((1, "nhat"), (2, "lightdir"), (3, "distance")):
+        if a[i] is not None:
+            rel = ((a[i] - b[i]).abs() / b[i].abs().clamp(min=1.0)).max().item()
+            assert rel <= 1.2e-7, (name, rel)                              # 1 ulp (unit vectors; |v| ~ 3)
+    for i, name in ((4, "g_sdf"), (5, "g_normal"), (6, "g_light_pos")):
+        if a[i] is None or b[i] is None:
+            assert a[i] is None and b[i] is None or collocated, name
+            continue
+        err = ((a[i] - b[i]).abs() / (b[i].abs() + b[i].abs().mean())).max().item()
+        print("shade_inputs", "collocated" if collocated else "offset", name, err)
+        assert err < 2e-5, (name, err)

@@ -236,3 +236,38 @@ def test_visibility_kernels_match_torch_formula_and_edge_cases():
     rc = Lib.pir_visibility_forward(_lib.ptr(sdf), _lib.ptr(nrm), _lib.ptr(d), _lib.ptr(L.reshape(-1).contiguous()),
                                     _lib.ptr(inv_s.reshape(1)), 1, 523, _lib.ptr(vis.detach()), _lib.stream_ptr())
     assert rc == 1
+
+
+def test_two_streams_overlap_without_sharing_scratch():
+    """Two get_all + get_all_backward calls enqueued on two streams of one GPU (they overlap: each is long enough to
+    still run when the other is launched) give the results of the serial calls bit for bit: scratch and workspace
+    caches are keyed by (device, stream)."""
+    from pir_amd import sdf_hip
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    pk = net.packed()
+    g = torch.Generator().manual_seed(21)
+    M = 150_000
+    xs = [(torch.rand(M, 3, generator=g) * 2 - 1).cuda() for _ in range(2)]
+    gs = [torch.randn(M, generator=g).cuda() for _ in range(2)]
+    gn = [torch.randn(M, 3, generator=g).cuda() for _ in range(2)]
+    serial = []
+    for i in range(2):
+        fw = pk.get_all(xs[i], want_feature=False)
+        serial.append((fw, sdf_hip.get_all_backward(pk, xs[i], gs[i], None, gn[i], True)))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    par = [None, None]
+    for rep in range(2):                      # second round: the per-stream buffers already exist
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                fw = pk.get_all(xs[i], want_feature=False)
+                par[i] = (fw, sdf_hip.get_all_backward(pk, xs[i], gs[i], None, gn[i], True))
+        torch.cuda.synchronize()
+        for i in range(2):
+            (s0, _, n0), (w0, b0, x0) = serial[i]
+            (s1, _, n1), (w1, b1, x1) = par[i]
+            assert torch.equal(s0, s1) and torch.equal(n0, n1) and torch.equal(x0, x1), (rep, i)
+            for a, b in zip(w0 + b0, w1 + b1):
+                assert torch.equal(a, b), (rep, i)
+    keys = {k[:2] for k in sdf_hip._bwd_scratch_cache}
+    assert len({k[1] for k in keys}) >= 3      # default stream + the two side streams each own a buffer
