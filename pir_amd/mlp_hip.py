@@ -249,6 +249,21 @@ def mlp_apply_eager(mod, inp):
     return x
 
 
+def _eager_from_weights(inp, wb, skip):
+    """mlp_apply_eager on explicit effective weights / biases (a differentiable function of all of them)."""
+    import numpy as np
+    import torch.nn.functional as F
+    n = len(wb) // 2
+    x = inp
+    for l in range(n):
+        if skip is not None and l == skip:
+            x = torch.cat([x, inp], dim=-1) / np.sqrt(2)
+        x = F.linear(x, wb[l], wb[n + l])
+        if l < n - 1:
+            x = F.relu(x)
+    return x
+
+
 _bwd_scratch_cache = {}
 BWD_CHUNK_POINTS = 131072
 _force_eager = 0
@@ -320,16 +335,28 @@ class _MlpFn(torch.autograd.Function):
         out = packed.forward_padded(xp)
         ctx.packed, ctx.xp, ctx.in_shape = packed, xp, inp.shape
         ctx.need_gx = inp.requires_grad
-        ctx.save_for_backward(*wb)
+        ctx.skip = mod.skip_in[0] if mod.skip_in else None
+        ctx.save_for_backward(inp, *wb)
         return out.reshape(*inp.shape[:-1], out.shape[-1])
 
     @staticmethod
     def backward(ctx, g_out):
-        wb = ctx.saved_tensors
+        inp, *wb = ctx.saved_tensors
         packed, xp = ctx.packed, ctx.xp
-        if torch.is_grad_enabled() and ctx.need_gx and packed.n_out <= 4:   # create_graph=True: keep it differentiable
-            res = _MlpBwdFn.apply(packed, xp, ctx.in_shape, g_out, *wb)
-            return (None, res[0], *res[1:])
+        if torch.is_grad_enabled():          # create_graph=True: the gradients must stay differentiable
+            if ctx.need_gx and packed.n_out <= 4:     # fused second order (tangent kernel) for d/d input
+                res = _MlpBwdFn.apply(packed, xp, ctx.in_shape, g_out, *wb)
+                return (None, res[0], *res[1:])
+            # no fused second-order path for this shape (wide outputs such as the 384-wide DINO field, or second
+            # derivatives w.r.t. the weights only): differentiate the eager expression so that nothing is silently
+            # cut out of the graph
+            with torch.enable_grad():
+                out = _eager_from_weights(inp, wb, ctx.skip)
+                wanted = [t for t in [inp] + list(wb) if t.requires_grad]
+                got = torch.autograd.grad(out, wanted, g_out.reshape(out.shape), create_graph=True, allow_unused=True)
+            it = iter(got)
+            grads = [next(it) if t.requires_grad else None for t in [inp] + list(wb)]
+            return (None, *grads)
         gx, gws, gbs = _run_backward(packed, xp, g_out, ctx.need_gx, [tuple(t.shape) for t in wb])
         g_in = gx[:, :packed.k0].reshape(ctx.in_shape) if ctx.need_gx else None
         return (None, g_in, *gws, *gbs)

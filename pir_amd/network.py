@@ -52,6 +52,17 @@ class WNLinear(nn.Module):
         return F.linear(x, self.effective_weight(), self.bias)
 
 
+def invalidate_packed(module):
+    """invalidate_packed for any pir_amd network (SDFNetwork, RenderingNetwork, BlendNetwork, DINONetwork) or a
+    container of them: needed only after writes through `.data`, which the version-keyed caches cannot see."""
+    for m in module.modules():
+        if isinstance(m, SDFNetwork):
+            m.invalidate_packed()
+        if getattr(m, "_packed_mlp", None) is not None:
+            m._packed_mlp = None
+            m._packed_mlp_key = None
+
+
 def _relu_mlp(mod, inp, keep_graph=True):
     """lin0..lin_last of a RenderingNetwork / BlendNetwork / DINONetwork on the concatenated input rows `inp`
     ([..., k0]; skip layers read [x | inp] / sqrt 2, ReLU after all but the last layer; src/network.py:232-243).
@@ -134,6 +145,13 @@ class SDFNetwork(nn.Module):
                 self._packed = PackedSdf(ws, bs)
             self._packed_key = key
         return self._packed
+
+    def invalidate_packed(self):
+        """Drop the packed weights.  The cache key is (data_ptr, version) of every parameter, which in-place writes
+        through autograd-visible tensors bump (optimizers, load_state_dict); writes through `.data` do NOT, so code
+        that edits `p.data` directly (EMA swaps, manual re-initialisation) must call this afterwards."""
+        self._packed = None
+        self._packed_key = None
 
     # ------------------------------------------------------------------ reference API
     def _forward_torch(self, inputs):
@@ -358,3 +376,15 @@ class DINONetwork(nn.Module):
         x = _relu_mlp(self, inp, keep_graph=is_training)
         x = self.output_scale * (x + self.output_bias)
         return x if is_training else x.detach()
+
+    def passback(self, points, feature, is_training=True):
+        """d feature / d points summed over the feature channels (reference: src/network.py:469-486); `feature` must
+        have been computed from `points` with is_training=True.  With is_training the result is differentiable once
+        more (through the eager expression of the MLP: the fused kernels have no second-order path for 384 outputs)."""
+        with torch.enable_grad():
+            points.requires_grad_(True)
+            (gradients,) = torch.autograd.grad(feature, points, torch.ones_like(feature), create_graph=is_training,
+                                               retain_graph=is_training, only_inputs=True)
+        if not is_training:
+            return feature.detach(), gradients.detach()
+        return feature, gradients

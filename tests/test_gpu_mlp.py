@@ -323,3 +323,34 @@ def test_blend_network_runs_zero_padded_on_the_fused_kernels():
     for k in g0:
         assert g0[k].shape == g1[k].shape
         assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-4, k
+
+
+def test_dino_double_backward_and_passback_stay_differentiable():
+    """The 384-wide DINO field has no fused second-order path: under create_graph=True its backward must stay in the
+    graph (through the eager expression) instead of silently returning constants.  passback (src/network.py:469-486)
+    differentiated once more against the eager module."""
+    from pir_amd import scene, mlp_hip
+    _, _, dino = scene.build_networks(seed=4, device="cuda")
+    g = torch.Generator().manual_seed(12)
+    pts0 = (torch.rand(300, 3, generator=g) - 0.5).cuda()
+    res = []
+    for mode in ("fused", "eager"):
+        dino.zero_grad()
+        p = pts0.clone().requires_grad_(True)
+        ctx = mlp_hip.eager_grad() if mode == "eager" else torch.enable_grad()
+        with ctx:
+            feat = dino(p, is_training=True)
+            if mode == "fused":
+                assert _graph_has(feat.grad_fn, "_MlpFn")
+            y, grads = dino.passback(p, feat, is_training=True)
+            assert grads.requires_grad                       # still differentiable
+            (grads.pow(2).sum() + 1e-3 * y.pow(2).sum()).backward()
+        res.append((grads.detach(), p.grad.clone(), {k: q.grad.clone() for k, q in dino.named_parameters()}))
+    (g0, p0, w0), (g1, p1, w1) = res
+    assert rel_err(g0.cpu().numpy(), g1.cpu().numpy()) < 1e-4
+    assert rel_err(p0.cpu().numpy(), p1.cpu().numpy()) < 1e-3
+    for k in w0:
+        assert w0[k].abs().max().item() > 0 and rel_err(w0[k].cpu().numpy(), w1[k].cpu().numpy()) < 1e-3, k
+    p = pts0.clone().requires_grad_(True)
+    y, grads = dino.passback(p, dino(p, is_training=True), is_training=False)
+    assert not y.requires_grad and not grads.requires_grad and grads.shape == (300, 3)

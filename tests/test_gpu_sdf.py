@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from conftest import load_golden, state_from_npz, rel_err
+from gpu_util import sdf_net
 
 pytestmark = pytest.mark.gpu
 
@@ -62,3 +63,20 @@ def test_empty_input():
     assert pk.forward(x).shape == (0,)
     s, f, n = pk.get_all(x)
     assert s.shape == (0,) and f.shape == (0, 256) and n.shape == (0, 3)
+
+
+def test_packed_cache_follows_parameter_writes():
+    """The packed weights are rebuilt after optimizer-style in-place updates; a write through `.data` is invisible to
+    the version key and needs invalidate_packed()."""
+    from pir_amd.network import invalidate_packed
+    net = sdf_net("sdf_full.npz")
+    x = torch.rand(100, 3).cuda() - 0.5
+    a = net.sdf(x).clone()
+    with torch.no_grad():
+        net.lin8.bias.add_(0.25)                 # bumps the version: picked up by itself
+    b = net.sdf(x)
+    assert (b - a - 0.25).abs().max().item() < 1e-6
+    net.lin8.bias.data.sub_(0.25)                # .data write: not visible to the key
+    invalidate_packed(net)
+    c = net.sdf(x)
+    assert (c - a).abs().max().item() < 1e-6
