@@ -37,6 +37,111 @@ __device__ __forceinline__ void store_tile(float (*dst)[kWgTile], const TileRegs
   }
 }
 
+#ifdef PIR_WG_LDSDMA
+// ---- A/B variant (round 2, slower: 19.3 vs 18.2 ms per 1 M points): operand staging by LDS-DMA (global_load_lds_dwordx4): no register hop, two LDS stages, one barrier per step.
+// A wave instruction moves 64 lanes x 16 B = two 512-byte tile rows; the LDS side is wave-uniform base + 16 * lane,
+// which is exactly the row-major [32][128] tile, the global side is per lane.  Lanes outside the operand (columns
+// beyond a 64-wide array, rows beyond a caller-owned array) read a zero quad instead.
+__device__ __align__(16) const float kZeroQuad[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma_tile(float (*dst)[kWgTile], const float* __restrict__ src, int ld, int col0, int row0,
+                                         int rows_valid) {
+  const int wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * kWgThreads + threadIdx.x;
+    const int r = idx >> 5, c4 = idx & 31;
+    const bool ok = col0 + 4 * c4 < ld && (rows_valid < 0 || row0 + r < rows_valid);
+    const float* g = ok ? src + (size_t)(row0 + r) * ld + col0 + 4 * c4 : kZeroQuad;
+    float* l = &dst[0][0] + (q * kWgThreads + 64 * wv) * 4;      // wave-uniform
+    __builtin_amdgcn_global_load_lds((const void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  }
+}
+
+// One workgroup = one (job, K slice): C tile 128x128 over the slice's points, both products of the job.
+// The operands of step s+1 stream into the other LDS stage while the MFMAs of step s run.
+__global__ void __launch_bounds__(kWgThreads, 2)
+wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __restrict__ slabs,
+             float* __restrict__ bias_slabs) {
+  __shared__ float Xs[2][kWgKPts][kWgTile];
+  __shared__ float Ys[2][kWgKPts][kWgTile];
+  const int job_id = blockIdx.x / ksplit, ks = blockIdx.x % ksplit;
+  const WgJob jb = jobs.j[job_id];
+  const int total_it = n_rows / kWgKPts;
+  const int it0 = (int)((long)ks * total_it / ksplit), it1 = (int)((long)(ks + 1) * total_it / ksplit);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wr = wv >> 1, wc = wv & 1, lo = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;
+  const int ncols_y = jb.ldy - jb.i0 < kWgTile ? jb.ldy - jb.i0 : kWgTile;
+  const bool wave_has_cols = 64 * wc < ncols_y;
+  const int nprod = jb.X2 ? 2 : 1;
+  const int nsteps = (it1 - it0) * nprod;
+  auto fetch = [&](int step) {
+    const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts, buf = step & 1;
+    dma_tile(Xs[buf], prod ? jb.X2 : jb.X1, prod ? 256 : jb.ldx, jb.o0, row0, prod ? -1 : jb.x1_rows);
+    dma_tile(Ys[buf], prod ? jb.Y2 : jb.Y1, jb.ldy, jb.i0, row0, prod ? -1 : jb.y1_rows);
+  };
+  if (nsteps > 0) {
+    fetch(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  for (int step = 0; step < nsteps; ++step) {
+    const int buf = step & 1;
+#ifndef PIR_ABL_WG_NOFETCH
+    if (step + 1 < nsteps) fetch(step + 1);      // lands in the other stage while this one is multiplied
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    if (jb.bias && step % nprod == 0) {
+      const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += Xs[buf][16 * half + r][col];
+    }
+    if (wave_has_cols) {
+#pragma unroll
+      for (int s = 0; s < kWgKPts / 2; ++s) {
+        const float a0 = Xs[buf][2 * s + kh][64 * wr + lo], a1 = Xs[buf][2 * s + kh][64 * wr + 32 + lo];
+        const float b0 = Ys[buf][2 * s + kh][64 * wc + lo], b1 = Ys[buf][2 * s + kh][64 * wc + 32 + lo];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's DMA for the next step has landed; after the barrier everybody's has, and nobody still reads `buf`
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef PIR_ABL_WG_NOBAR
+    __syncthreads();
+#endif
+  }
+  float* slab = slabs + ((size_t)ks * jobs.n + job_id) * kWgTile * kWgTile;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 64 * wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const int col = 64 * wc + 32 * b + lo;
+        slab[row * kWgTile + col] = acc[a][b][r];
+      }
+  if (jb.bias) {
+    float* red = &Xs[0][0][0];
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 128)
+      bias_slabs[((size_t)ks * jobs.n + job_id) * kWgTile + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
+  }
+}
+#else   // default: global -> registers -> LDS with the register prefetch one step ahead
 // One workgroup = one (job, K slice): C tile 128x128 over the slice's points, both products of the job.
 // The operands of step s+1 are fetched into registers while the MFMAs of step s run from LDS.
 __global__ void __launch_bounds__(kWgThreads)
@@ -120,6 +225,8 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __
       bias_slabs[((size_t)ks * jobs.n + job_id) * kWgTile + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 128];
   }
 }
+
+#endif
 
 // row 0 of dW8 and db8[0]:  sum_pts (g_sdf a7 + a7-tangent),  sum_pts g_sdf   -> partial[block][257]
 constexpr int kRow0Blocks = 1024;

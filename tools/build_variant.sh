@@ -1,13 +1,16 @@
 #!/bin/bash
-# development aid: build variants/<name>.so with extra -D flags:  tools/build_variant.sh name -DPIR_ABL_NOSTORE ...
+# Build an A/B variant of libpir_hip.so with extra compiler flags:  tools/build_variant.sh NAME -DFLAG [-DFLAG ...]
+# -> variants/NAME/libpir_hip.so (load it with PIR_HIP_LIB=variants/NAME/libpir_hip.so).  variants/ is not committed.
 set -e
-name=$1; shift
 cd "$(dirname "$0")/.."
-mkdir -p variants/obj_$name
-for f in sdf_eval trace ggx sdf_backward wgrad visibility mlp prof; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment "$@" -c pir_amd/csrc/$f.hip -o variants/obj_$name/$f.o &
+name=$1; shift
+out=variants/$name
+mkdir -p "$out"
+pids=()
+for f in sdf_eval trace ggx sdf_backward wgrad visibility mlp shade_inputs prof; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment "$@" -c pir_amd/csrc/$f.hip -o "$out/$f.o" &
+  pids+=($!)
 done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$name.so variants/obj_$name/*.o
-rm -rf variants/obj_$name
-echo built variants/$name.so
+for p in "${pids[@]}"; do wait "$p"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$out/libpir_hip.so" "$out"/*.o
+echo "built $out/libpir_hip.so"
