@@ -251,7 +251,11 @@ def main():
     # MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is; tools/kprof.py is the profiled program),
     # scaled to this run's points per launch.  None when no PMC pass exists for that kernel.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        pmc = {}
+        for fn in ("r01_pmc_traffic.json", "r02_pmc_traffic.json"):      # the newest pass of each kernel wins
+            path = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(path):
+                pmc.update(json.load(open(path)))
         if roofline and names[dom] in pmc:
             roofline["traffic"] = round(pmc[names[dom]]["hbm_bytes_per_point"] * units[dom] / launches[dom])
             roofline["traffic_unit"] = "bytes/launch (PMC bytes/point x points/launch)"

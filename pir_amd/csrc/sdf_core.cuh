@@ -1,5 +1,5 @@
-// SDF-MLP core for gfx950: a workgroup is a PAIR of wavefronts (128 threads) that pushes
-// two "operand sets" of 32 points each through the 8x256 softplus MLP of PIR's SDFNetwork
+// SDF-MLP core for gfx950: a workgroup of FOUR wavefronts (256 threads, two workgroups per CU = two waves per
+// SIMD) pushes two "operand sets" of 32 points each through the 8x256 softplus MLP of PIR's SDFNetwork
 // (reference: src/network.py:8-142) on the exact-f32 MFMA v_mfma_f32_32x32x2_f32.
 //
 // Orientation: activations are the B operand (k = feature, column = point), weights the A
@@ -7,7 +7,10 @@
 // lane and the neuron in the register -- exactly the B-operand shape of the next layer.
 // Activations live in LDS as [k-step][lane] images (one ds_read_b128 = 4 k-steps), weights
 // stream from L2 in a pre-packed fragment order (one global_load_dwordx4 = 4 k-steps).
-// Each wave owns 4 of the 8 output tiles for both sets: 128 accumulator registers.
+// Each wave owns 2 of the 8 output tiles for both sets: 64 accumulator registers.
+// Measured alternatives (round 2): with the weight stream compiled out (every k-block re-reads
+// one resident 1 KB block) the forward gains 1.6 % and get_all 1.9 %, the ceiling for any LDS weight-staging scheme;
+// point loads from SoA planes instead of the reference's AoS [M,3], or no point loads at all, change nothing.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -96,7 +96,13 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
     const long base = tile * kWgPts;
     const long P = base + 32 * (w & 1) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
+#ifdef PIR_AB_X_SOA      // A/B (timing only): read the same buffer as three planes [3][M] (SoA, 4-byte coalesced)
+    if (P < M) { x0 = x[P]; x1 = x[M + P]; x2 = x[2 * M + P]; }
+#elif defined(PIR_AB_X_NONE)   // A/B bound: no point loads at all
+    if (P < M) { x0 = 1e-3f * (float)(P & 1023) - 0.5f; x1 = 0.3f; x2 = -0.2f; }
+#else
     if (P < M) { x0 = x[3 * P]; x1 = x[3 * P + 1]; x2 = x[3 * P + 2]; }
+#endif
     forward_hidden<kNormal>(lds, pk, x0, x1, x2, scratch);
     sdf_head(lds, pk);
     if (FLAGS & kWantFeat) feature_head(lds, pk, feat, base, M);

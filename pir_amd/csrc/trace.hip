@@ -76,7 +76,12 @@ trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* _
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (e < count) {
       const int r = lin[e];
+#ifdef PIR_AB_X_SOA      // A/B (timing only): the ray-state gather from three planes of the same buffer
+      const int NN = ws.counters[0];
+      x0 = pts[r]; x1 = pts[NN + r]; x2 = pts[2 * NN + r];
+#else
       x0 = pts[3 * r]; x1 = pts[3 * r + 1]; x2 = pts[3 * r + 2];
+#endif
     }
     eval_tile(lds, pk, x0, x1, x2);
     if (threadIdx.x < kWgPts) {
@@ -96,8 +101,14 @@ trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* _
           keep = true;
           if (it < max_iters) {
             dis[r] = add_rn(a, v);
+#ifdef PIR_AB_X_SOA
+            const int NN = ws.counters[0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pts[c * NN + r] = add_rn(pts[c * NN + r], mul_rn(ray_d[c * NN + r], v));
+#else
 #pragma unroll
             for (int c = 0; c < 3; ++c) pts[3 * r + c] = add_rn(pts[3 * r + c], mul_rn(ray_d[3 * r + c], v));
+#endif
           }
         }
       }

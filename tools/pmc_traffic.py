@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counter_collection CSVs) of tools/kprof*.py into HBM
-bytes per point per kernel and merge them into profiles/r01_pmc_traffic.json.
+bytes per point per kernel and merge them into profiles/r02_pmc_traffic.json (PMC_OUT overrides the file name).
 
     python tools/pmc_traffic.py fetch.csv write.csv M      (M = points of the profiled program; the backward
                                                             kernels run on chunks of at most 131072 of them)
@@ -37,7 +37,7 @@ def main():
     fetch, nf = per_launch(sys.argv[1], "FETCH_SIZE")
     write, _ = per_launch(sys.argv[2], "WRITE_SIZE")
     pts = float(sys.argv[3])
-    out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+    out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", os.environ.get("PMC_OUT", "r02_pmc_traffic.json"))
     out = json.load(open(out_path)) if os.path.exists(out_path) else {}
     for k in fetch:
         if SUFFIX and not k.startswith("mlp_"):
