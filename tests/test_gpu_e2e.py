@@ -64,11 +64,11 @@ def test_render_camera_tile_matches_reference(tag):
     loss.backward()
     if use_vis:
         mostly_close("vis")
-        assert rel_err(pl.light_offset.weight.grad.cpu().numpy(), d["offset.g_offset"]) < 1e-3
+        assert rel_err(pl.light_offset.weight.grad.cpu().numpy(), d["offset.g_offset"]) < 2e-5
     assert abs(pl.light.grad.item() - float(d[f"{tag}.g_light"])) < 2e-4 * abs(float(d[f"{tag}.g_light"]))
     for k, p in net.named_parameters():
         ref = d[f"{tag}.g.sdf.{k}"]
-        assert rel_err(grad_np(p, ref.shape), ref) < 1e-3, k
+        assert rel_err(grad_np(p, ref.shape), ref) < 3e-4, k
     for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
         for k, p in mats[nm].named_parameters():
             ref = d[f"{tag}.g.{nm}.{k}"]
@@ -127,9 +127,9 @@ def test_backward_linearity_large():
     a = sdf_hip.get_all_backward(net.packed(), x, gs[0], None, gn[0], True)
     b = sdf_hip.get_all_backward(net.packed(), x, gs[1], None, gn[1], True)
     c = sdf_hip.get_all_backward(net.packed(), x, gs[0] + gs[1], None, gn[0] + gn[1], True)
-    assert rel_err((a[2] + b[2]).cpu().numpy(), c[2].cpu().numpy()) < 1e-5
+    assert rel_err((a[2] + b[2]).cpu().numpy(), c[2].cpu().numpy()) < 1e-6
     for wa, wb, wc in zip(a[0] + a[1], b[0] + b[1], c[0] + c[1]):
-        assert rel_err((wa + wb).cpu().numpy(), wc.cpu().numpy()) < 2e-4
+        assert rel_err((wa + wb).cpu().numpy(), wc.cpu().numpy()) < 1e-5
 
 
 def test_ggx_million_points_vs_torch_formula():

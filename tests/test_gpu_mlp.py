@@ -97,14 +97,14 @@ def test_material_backward_matches_eager(P):
             (out * w).sum().backward()
             res.append((out.detach(), [l.grad for l in leaves], {k: p.grad.clone() for k, p in net.named_parameters()}))
         (o0, gl0, gp0), (o1, gl1, gp1) = res
-        assert rel_err(o0.cpu().numpy(), o1.cpu().numpy()) < 2e-5
+        assert rel_err(o0.cpu().numpy(), o1.cpu().numpy()) < 2e-6
         for a, b, nm in zip(gl0, gl1, ("points", "normals", "geo_f", "dino_f")):
             if b is None:
                 assert a is None or float(a.abs().max()) == 0.0, nm
                 continue
-            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4, (name, nm)
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-6, (name, nm)
         for k in gp0:
-            assert rel_err(gp0[k].cpu().numpy(), gp1[k].cpu().numpy()) < 1e-4, (name, k)
+            assert rel_err(gp0[k].cpu().numpy(), gp1[k].cpu().numpy()) < 5e-6, (name, k)
 
 
 def _graph_has(fn, name):
@@ -212,7 +212,7 @@ def test_fused_material_networks_match_reference_fixture():
         assert mlp_hip.module_supported(net)
         with torch.no_grad():
             y = MU.call(net, name, pts, nrm, geo, dino)
-        assert rel_err(y.cpu().numpy(), d[f"{name}.out"]) < 2e-5, name
+        assert rel_err(y.cpu().numpy(), d[f"{name}.out"]) < 5e-6, name
         if name == "dino_network":
             continue
         leaves = [t.clone().requires_grad_(True) for t in (pts, nrm, geo, dino)]
@@ -220,11 +220,11 @@ def test_fused_material_networks_match_reference_fixture():
         (y * torch.from_numpy(d[f"{name}.cw"]).cuda()).sum().backward()
         for nm, t in zip(("pts", "nrm", "geo", "dino"), leaves):
             if f"{name}.g_{nm}" in d.files:
-                assert rel_err(t.grad.cpu().numpy(), d[f"{name}.g_{nm}"]) < 2e-4, (name, nm)
+                assert rel_err(t.grad.cpu().numpy(), d[f"{name}.g_{nm}"]) < 5e-6, (name, nm)
         for k, p in net.named_parameters():
             ref = d[f"{name}.g.{k}"]
             g = p.grad.cpu().numpy()
-            assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 2e-4, (name, k)
+            assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 1e-5, (name, k)
 
 
 def test_mlp_entry_points_reject_bad_arguments():
@@ -284,7 +284,7 @@ def test_dino_field_backward_matches_eager(P):
         (out * w).sum().backward()
         res.append((out.detach(), p.grad.clone(), {k: q.grad.clone() for k, q in dinonet.named_parameters()}))
     (o0, p0, g0), (o1, p1, g1) = res
-    assert rel_err(o0.cpu().numpy(), o1.cpu().numpy()) < 2e-5
+    assert rel_err(o0.cpu().numpy(), o1.cpu().numpy()) < 2e-6
     row = (p0 - p1).abs().max(-1).values / p1.abs().max()
     assert (row > 1e-4).float().mean().item() < 2e-3
     errs = [rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) for k in g0]
@@ -319,10 +319,10 @@ def test_blend_network_runs_zero_padded_on_the_fused_kernels():
     (y0, l0, g0), (y1, l1, g1) = res
     assert rel_err(y0.cpu().numpy(), y1.cpu().numpy()) < 2e-5 and rel_err(y_inf.cpu().numpy(), y1.cpu().numpy()) < 2e-5
     for a, b in zip(l0, l1):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-4
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
     for k in g0:
         assert g0[k].shape == g1[k].shape
-        assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 2e-4, k
+        assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k
 
 
 def test_dino_double_backward_and_passback_stay_differentiable():

@@ -10,7 +10,7 @@ def test_edges_and_indirect_lighting_match_reference():
     import next_rows_util
     # Tolerances as in test_gpu_e2e: 97 % of the pixels within 1e-4 (max-normalised), the rest (tracer threshold
     # sensitivity amplified by the 2^9-frequency encodings) within 2e-3; hit points within 2.5e-4.
-    next_rows_util.run("cuda", tol=1e-4, grad_tol=2e-3, point_tol=5e-5, exact_edges=False)
+    next_rows_util.run("cuda", tol=1e-4, grad_tol=5e-4, point_tol=5e-5, exact_edges=False)   # achieved: 2.0e-4
 
 
 def test_full_render_camera_with_edges_and_indirect_runs_and_is_deterministic():
@@ -52,7 +52,7 @@ def test_training_step_matches_reference():
     # Material-network gradients get a wider bound: the albedo MLP encodes the hit point with frequencies up to 2^9,
     # so the tracer's legitimate 1e-4 differences in a few hit points (the CPU run of the same
     # code meets 3e-4 on every gradient) move them by a few 1e-3.
-    train_step_util.run("cuda", tol=1e-4, grad_tol=2e-3, exact=False, mat_grad_tol=1e-2)
+    train_step_util.run("cuda", tol=1e-4, grad_tol=1.5e-3, exact=False, mat_grad_tol=1e-2)   # achieved: 7.5e-4 / 8.9e-3
 
 
 def test_visibility_cache_round_trip(tmp_path):
@@ -112,5 +112,5 @@ def test_training_step_full_size_materials_fused_vs_eager():
     for k in ("loss", "img_loss", "eik_loss", "roughrange_loss", "smoothness_loss"):
         assert abs(o0[k] - o1[k]) <= 2e-4 * abs(o1[k]) + 1e-9, (k, o0[k], o1[k])
     errs = {k: rel_err(g0[k], g1[k]) for k in g0}
-    assert float(np.median(list(errs.values()))) < 1e-3 and max(errs.values()) < 3e-2, \
+    assert float(np.median(list(errs.values()))) < 3e-6 and max(errs.values()) < 1e-5, \
         sorted(errs.items(), key=lambda kv: -kv[1])[:5]

@@ -27,7 +27,7 @@ def test_forward_matches_reference_fixture(weights):
     ref = O.sdf_forward(layers, x).detach().numpy() if weights != "sdf_full.npz" else d["forward"]
     sdf, feat = pk.forward(x.cuda(), want_feature=True)
     assert np.abs(sdf.cpu().numpy() - ref[:, 0]).max() < 2e-6 * max(1.0, np.abs(ref[:, 0]).max())
-    assert rel_err(feat.cpu().numpy(), ref[:, 1:]) < 1e-5
+    assert rel_err(feat.cpu().numpy(), ref[:, 1:]) < 3e-6
     sdf2 = pk.forward(x.cuda())
     assert torch.equal(sdf2, sdf)
 
@@ -43,7 +43,7 @@ def test_get_all_matches_oracle(M):
     sdf, feat, normal = pk.get_all(x.cuda(), want_feature=True)
     assert np.abs(sdf.cpu().numpy() - y[:, 0].numpy()).max() < 5e-6
     assert rel_err(feat.cpu().numpy(), f.numpy()) < 1e-5
-    assert rel_err(normal.cpu().numpy(), n.numpy()) < 1e-4
+    assert rel_err(normal.cpu().numpy(), n.numpy()) < 5e-6
     sdf2, none, normal2 = pk.get_all(x.cuda(), want_feature=False)
     assert none is None and torch.equal(sdf2, sdf) and torch.equal(normal2, normal)
 
@@ -53,8 +53,8 @@ def test_get_all_reference_fixture():
     d = load_golden("sdf_full.npz")
     sdf, feat, normal = pk.get_all(torch.from_numpy(d["x"]).cuda())
     assert np.abs(sdf.cpu().numpy() - d["sdf"][:, 0]).max() < 5e-6
-    assert rel_err(feat.cpu().numpy(), d["feature"]) < 1e-5
-    assert rel_err(normal.cpu().numpy(), d["normal"]) < 1e-4
+    assert rel_err(feat.cpu().numpy(), d["feature"]) < 2e-6
+    assert rel_err(normal.cpu().numpy(), d["normal"]) < 5e-6
 
 
 def test_empty_input():
