@@ -69,7 +69,7 @@ class PackedSdf:
 
 
 _bwd_scratch_cache = {}
-BWD_CHUNK_POINTS = 131072
+BWD_CHUNK_POINTS = 262144   # the C ABI caps a pass at 262 144 points (8.7 GB of scratch); fewer passes = fewer slab reductions
 
 
 def backward_scratch_for(device, chunk_points: int = None) -> torch.Tensor:
