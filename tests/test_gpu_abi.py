@@ -140,3 +140,33 @@ def test_shade_inputs_kernel_matches_torch_expressions(collocated):
         err = ((a[i] - b[i]).abs() / (b[i].abs() + b[i].abs().mean())).max().item()
         print("shade_inputs", "collocated" if collocated else "offset", name, err)
         assert err < 2e-5, (name, err)
+
+
+def test_shade_inputs_abi_edge_cases():
+    """P = 0 does nothing, missing required pointers are rejected, and render_normal_and_color on a view without a
+    single hit (fused path never entered) returns all-zero images."""
+    from pir_amd import _lib, scene
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer.raytracer import RayTracer, Camera, render_camera
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    L = _lib.lib()
+    S = _lib.stream_ptr()
+    assert L.pir_shade_inputs_forward(0, None, None, None, 0, None, None, None, S) == 0
+    assert L.pir_shade_inputs_backward(0, None, None, None, None, 0, None, None, None, None, None, None, None, S) == 0
+    t = torch.zeros(4, 3, device="cuda")
+    assert L.pir_shade_inputs_forward(4, _lib.ptr(t), None, _lib.ptr(t), 0, _lib.ptr(t), None, _lib.ptr(t), S) == 1
+    assert L.pir_shade_inputs_forward(-1, _lib.ptr(t), _lib.ptr(t), _lib.ptr(t), 0, _lib.ptr(t), None, _lib.ptr(t), S) == 1
+    # g_sdf wanted but no ray_d given
+    assert L.pir_shade_inputs_backward(4, _lib.ptr(t), _lib.ptr(t), None, _lib.ptr(t), 0, None, None, None, None,
+                                       _lib.ptr(t), _lib.ptr(t[:, 0].contiguous()), None, S) == 1
+    sdf, mats, dino = scene.build_networks(seed=0, device="cuda")
+    cam0 = scene.make_camera(16, 16, device="cuda")
+    W2C = cam0.W2C.clone()
+    W2C[0, 3] = 50.0                                   # the object is far outside the frustum: no ray hits the unit sphere
+    cam = Camera(16, 16, cam0.K, W2C)
+    res = render_camera(cam, sdf, RayTracer(), mats, dino, make_render_fn(GGXColocatedRenderer(use_cuda=True)),
+                        fill_holes=False, handle_edges=False, inv_s=torch.full((1, 1), scene.INV_S, device="cuda"),
+                        render_visibility=True, light_pos=cam.get_light_pos(mats["point_light_network"].offset),
+                        indirect_warmup=True, is_training=True)
+    assert not res["convergent_mask"].any()
+    assert res["color"].abs().max().item() == 0 and res["vis"].abs().max().item() == 0 and res["normal"].shape == (16, 16, 3)
