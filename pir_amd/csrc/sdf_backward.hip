@@ -134,6 +134,7 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       gemm_phase_pre<kTPW, false, true>(pk.mats, kFwd[l], kTPW * w, lds, l == 0 ? kActKB : 0, acc, pre, true,
                                         l < 7 ? kFwd[l + 1] : kRev[7]);
       __syncthreads();
+      PIR_PRIO_HI();
       const float* bias = pk.vecs + kVecBias + 256 * l;
 #pragma unroll
       for (int t = 0; t < kTPW; ++t) {
@@ -161,6 +162,7 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
         }
         __builtin_amdgcn_sched_barrier(0);   // keep one tile's loads/stores in flight at a time (register pressure)
       }
+      PIR_PRIO_LO();
       __syncthreads();
     }
 
@@ -193,6 +195,7 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     for (int l = 8; l >= 1; --l) {
       // acc = (u_l, y_l): gradients w.r.t. the input of layer l  ->  (q_{l-1}, zb_{l-1})
       const int m = l - 1;
+      PIR_PRIO_HI();
 #pragma unroll
       for (int t = 0; t < kTPW; ++t) {
         const int T = kTPW * w + t;
@@ -216,6 +219,7 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
         }
         __builtin_amdgcn_sched_barrier(0);
       }
+      PIR_PRIO_LO();
       __syncthreads();
       if (m >= 1) {
         zero_acc(acc);

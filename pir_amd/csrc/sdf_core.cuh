@@ -97,6 +97,20 @@ __host__ __device__ constexpr int pe_column(int slot, int h) {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// Epilogues (VALU / memory phases) run at wave priority 1 so that they win issue arbitration against the co-resident
+// wave's GEMM phase and get back to the matrix pipe sooner: get_all +0.8 %, bwd_sweep +1.7 % (-DPIR_EPI_PRIO=0 is the
+// A/B switch; priority 3 measures the same as 1).
+#ifndef PIR_EPI_PRIO
+#define PIR_EPI_PRIO 1
+#endif
+#if PIR_EPI_PRIO > 0
+#define PIR_PRIO_HI() __builtin_amdgcn_s_setprio(PIR_EPI_PRIO)
+#define PIR_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define PIR_PRIO_HI()
+#define PIR_PRIO_LO()
+#endif
+
 // ---- LDS image ------------------------------------------------------------------------------
 struct Lds {
   f32x4 act[kSets][kSetKB][64];   // 2 x 37 KB

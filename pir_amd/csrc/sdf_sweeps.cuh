@@ -31,7 +31,9 @@ __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, fl
     const Prod p = kFwd[l];
     gemm_phase_pre<kTPW, false, true>(pk.mats, p, kTPW * w, lds, l == 0 ? kActKB : 0, acc, pre, l < 7, kFwd[l < 7 ? l + 1 : l]);
     __syncthreads();   // every read of the previous activations is done
+    PIR_PRIO_HI();
     epilogue_softplus<STORE>(lds, acc, pk.vecs + kVecBias + 256 * l, scratch + (size_t)l * kScratchLayerF4);
+    PIR_PRIO_LO();
     __syncthreads();
   }
 }
@@ -187,7 +189,9 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
     gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[l], kTPW * w, lds, 0, acc, pre, l >= 2, kRev[l >= 2 ? l - 1 : l]);
     if (l == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
     __syncthreads();
+    PIR_PRIO_HI();
     epilogue_mul_dact(lds, acc, scratch + (size_t)(l - 1) * kScratchLayerF4);
+    PIR_PRIO_LO();
     __syncthreads();
   }
   if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
