@@ -291,6 +291,206 @@ wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, co
   }
 }
 
+// ---- 256 x 256 C tiles (a whole 256 x 256 layer per workgroup) ------------------------------------------------
+// The 128 x 128 kernel above spends 21 % of its time staging operands: a 128 x 128 fp32 tile step moves 32 KB for
+// 1 MFLOP (32 FLOP/B).  One workgroup of 8 waves per 256 x 256 tile moves 64 KB for 4 MFLOP per step: half the loads,
+// LDS writes and barriers per MFMA.  Each wave owns a 64 (outputs) x 128 (inputs) block = 8 accumulator tiles.
+// Used for the SDF layers whose operands are all 256 wide (layers 1..7 and the feature rows of lin8).
+constexpr int kW2Threads = 512;
+constexpr int kW2Tile = 256;
+
+struct TileRegs2 { f32x4 v[4]; };
+// 32 rows x 256 floats of a [rows][256] array (thread t holds float4 #(q*512 + t), q < 4)
+__device__ __forceinline__ void load_tile2(TileRegs2& t, const float* __restrict__ src, int ld, int row0,
+                                           int rows_valid) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * kW2Threads + threadIdx.x;
+    const int r = idx >> 6, c4 = idx & 63;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (4 * c4 < ld && (rows_valid < 0 || row0 + r < rows_valid))
+      v = *reinterpret_cast<const f32x4*>(src + (size_t)(row0 + r) * ld + 4 * c4);
+    t.v[q] = v;
+  }
+}
+__device__ __forceinline__ void store_tile2(float (*dst)[kW2Tile], const TileRegs2& t) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * kW2Threads + threadIdx.x;
+    *reinterpret_cast<f32x4*>(&dst[idx >> 6][4 * (idx & 63)]) = t.v[q];
+  }
+}
+
+// K slices per job: job j owns workgroups / slabs first[j] .. first[j+1]-1 (a job with a narrow operand does less
+// work per step and gets proportionally fewer slices, so that all workgroups finish together).
+struct Wg2Split { int first[12]; };
+
+__global__ void __launch_bounds__(kW2Threads, 2)
+wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float* __restrict__ slabs,
+                float* __restrict__ bias_slabs) {
+  __shared__ float Xs[kWgKPts][kW2Tile];
+  __shared__ float Ys[kWgKPts][kW2Tile];
+  int job_id = 0;
+  while (job_id + 1 < jobs.n && (int)blockIdx.x >= sp.first[job_id + 1]) ++job_id;
+  const int ks = blockIdx.x - sp.first[job_id], ksplit = sp.first[job_id + 1] - sp.first[job_id];
+  const WgJob jb = jobs.j[job_id];
+  const int total_it = n_rows / kWgKPts;
+  const int it0 = (int)((long)ks * total_it / ksplit), it1 = (int)((long)(ks + 1) * total_it / ksplit);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int wr = wv >> 1, wc = wv & 1, lo = lane & 31, kh = lane >> 5;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bsum = 0.f;
+  const int nprod = jb.X2 ? 2 : 1;
+  const int nsteps = (it1 - it0) * nprod;
+  TileRegs2 tx, ty;
+  auto fetch = [&](int step) {
+    const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts;
+    load_tile2(tx, prod ? jb.X2 : jb.X1, 256, row0, prod ? -1 : jb.x1_rows);
+    load_tile2(ty, prod ? jb.Y2 : jb.Y1, jb.ldy, row0, prod ? -1 : jb.y1_rows);
+  };
+  if (nsteps > 0) fetch(0);
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();
+    store_tile2(Xs, tx);
+    store_tile2(Ys, ty);
+    __syncthreads();
+    if (step + 1 < nsteps) fetch(step + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (jb.bias && step % nprod == 0) {
+      const int col = threadIdx.x & 255, half = threadIdx.x >> 8;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bsum += Xs[16 * half + r][col];
+    }
+    if (jb.ldy >= kW2Tile) {
+#pragma unroll
+      for (int s2 = 0; s2 < kWgKPts / 2; ++s2) {
+        const float a0 = Xs[2 * s2 + kh][64 * wr + lo], a1 = Xs[2 * s2 + kh][64 * wr + 32 + lo];
+        float b[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = Ys[2 * s2 + kh][128 * wc + 32 * t + lo];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[t], acc[1][t], 0, 0, 0);
+        }
+      }
+    } else if (jb.ldy < kW2Tile) {     // the 64-wide encoding operand of layer 0: every wave takes 32 output rows
+#pragma unroll
+      for (int s2 = 0; s2 < kWgKPts / 2; ++s2) {
+        const float a0 = Xs[2 * s2 + kh][32 * wv + lo];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const float bt = Ys[2 * s2 + kh][32 * t + lo];
+          acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float* slab = slabs + (size_t)blockIdx.x * kW2Tile * kW2Tile;
+  if (jb.ldy >= kW2Tile) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = 64 * wr + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int col = 128 * wc + 32 * t + lo;
+          slab[row * kW2Tile + col] = acc[a][t][r];
+        }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = 32 * wv + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        slab[row * kW2Tile + 32 * t + lo] = acc[0][t][r];
+      }
+  }
+  if (jb.bias) {
+    __syncthreads();
+    float* red = &Xs[0][0];
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 256)
+      bias_slabs[(size_t)blockIdx.x * kW2Tile + threadIdx.x] = red[threadIdx.x] + red[threadIdx.x + 256];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad256_reduce_kernel(WgJobs jobs, Wg2Split sp, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
+                       GradOut out) {
+  constexpr int kParts = 64;   // blocks per C tile (1024 elements each)
+  const int job_id = blockIdx.x / kParts, part = blockIdx.x % kParts;
+  const WgJob jb = jobs.j[job_id];
+  const int ksplit = sp.first[job_id + 1] - sp.first[job_id];
+  const size_t stride = (size_t)kW2Tile * kW2Tile;
+  const float* base = slabs + (size_t)sp.first[job_id] * kW2Tile * kW2Tile;
+  for (int e = part * 1024 + threadIdx.x; e < (part + 1) * 1024; e += 256) {
+    const int o = e / kW2Tile, i = e % kW2Tile;
+    if (o >= jb.rows || i >= jb.i_limit) continue;
+    float s = 0.f;
+    for (int k = 0; k < ksplit; ++k) s += base[k * stride + e];
+    out.w[jb.layer][(size_t)(jb.row_off + o) * jb.cols + jb.col_off + i] += jb.scale * s;
+  }
+  if (jb.bias && part == 0) {
+    const int o = threadIdx.x;
+    if (o < jb.rows) {
+      float s = 0.f;
+      for (int k = 0; k < ksplit; ++k) s += bias_slabs[(size_t)(sp.first[job_id] + k) * kW2Tile + o];
+      out.b[jb.layer][jb.row_off + o] += s;
+    }
+  }
+}
+
+// Jobs: whole-layer 256 x 256 products (o0 = i0 = 0, ldx = 256, ldy = 256 or 64).
+int wgrad256_run(const WgJobs& jobs, int n_rows, int n_points, const WgFixed& fx, const GradOut& out, int prof_id,
+                 void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (jobs.n < 1 || jobs.n > 10 || n_rows < kWgKPts || (n_rows % kWgKPts)) return PIR_ERR_ARG;
+  // One resident workgroup per CU (64 KB LDS, 512 threads at 256 registers).  Work units per 32 points: 20 for a
+  // job with two products over full-width operands, 12 for the 64-wide layer-0 operand (a quarter of the MFMAs, but
+  // its steps are bound by the latency of the operand fetch: 4.6 us against 7.9 us measured), half for a single
+  // product (the feature rows of lin8); every job gets K slices in proportion, as many as fill one round of the CUs,
+  // so that all workgroups finish together.
+  int cost[10], total = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    cost[j] = (jobs.j[j].ldy < kW2Tile ? 6 : 10) * (jobs.j[j].X2 ? 2 : 1);
+    total += cost[j];
+  }
+  const int steps = n_rows / kWgKPts;
+  const long slab_cap = (long)kKSplitMax * kMaxJobs * kWgTile * kWgTile / ((long)kW2Tile * kW2Tile);   // slabs that fit
+  long slots = pir_num_cus();
+  if (slots > slab_cap) slots = slab_cap;
+  Wg2Split sp;
+  int n_wg = 0;
+  for (int j = 0; j < jobs.n; ++j) {
+    int k = (int)(slots * cost[j] / total);
+    const int kmax = steps / 8 > 0 ? steps / 8 : 1;          // at least 8 K steps per slice
+    if (k > kmax) k = kmax;
+    if (k < 1) k = 1;
+    sp.first[j] = n_wg;
+    n_wg += k;
+  }
+  sp.first[jobs.n] = n_wg;
+  for (int j = jobs.n + 1; j < 12; ++j) sp.first[j] = n_wg;
+  {
+    PirProfScope prof(prof_id, (double)n_points, stream_);
+    hipLaunchKernelGGL(wgrad256_kernel, dim3(n_wg), dim3(kW2Threads), 0, stream, jobs, sp, n_rows, fx.slabs,
+                       fx.bias_slabs);
+  }
+  hipLaunchKernelGGL(wgrad256_reduce_kernel, dim3(jobs.n * 64), dim3(256), 0, stream, jobs, sp, fx.slabs, fx.bias_slabs,
+                     out);
+  return pir_check_launch();
+}
+
 static size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr size_t kSlabBytes = (size_t)kKSplitMax * kMaxJobs * kWgTile * kWgTile * 4;
 constexpr size_t kBiasSlabBytes = (size_t)kKSplitMax * kMaxJobs * kWgTile * 4;
@@ -381,9 +581,26 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
     const int n_rows = (n + 31) / 32 * 32;
     int rc = pir_internal_bwd_sweep(packed, x, g_sdf, g_feat, g_normal, base, n, &sc, g_x, stream_);
     if (rc != PIR_OK) return rc;
-    WgJobs jobs;
+    WgJobs jobs, big;     // whole-layer 256 x 256 tiles (`big`); the 128 x 128 job list stays for the A/B build
     jobs.n = 0;
+    big.n = 0;
+#ifdef PIR_WG_TILE128      // A/B: the round-1 tiling for every layer
+    const int first_big = 9;
+#else
+    const int first_big = 0;
+#endif
     for (int l = 0; l < 8; ++l) {
+      if (l >= first_big) {
+        WgJob& j = big.j[big.n++];
+        j.X1 = sc.Zb(l); j.X2 = sc.Q(l);
+        j.Y1 = l == 0 ? sc.E : sc.A(l - 1);
+        j.Y2 = l == 0 ? sc.Ed : sc.Ad(l - 1);
+        j.ldx = 256; j.ldy = l == 0 ? 64 : 256; j.x1_rows = -1; j.y1_rows = -1; j.o0 = 0; j.i0 = 0;
+        j.layer = l; j.row_off = 0; j.rows = rows[l]; j.cols = cols[l]; j.col_off = 0; j.i_limit = cols[l];
+        j.scale = l == 4 ? 0.70710678118654752440f : 1.0f;
+        j.bias = 1;
+        continue;
+      }
       const int ni = l == 0 ? 1 : 2;
       for (int ot = 0; ot < 2; ++ot)
         for (int itl = 0; itl < ni; ++itl) {
@@ -400,6 +617,12 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
         }
     }
     if (g_feat) {
+      if (first_big <= 8) {
+        WgJob& j = big.j[big.n++];
+        j.X1 = g_feat + (size_t)base * 256; j.X2 = nullptr; j.Y1 = sc.A(7); j.Y2 = nullptr;
+        j.ldx = 256; j.ldy = 256; j.x1_rows = n; j.y1_rows = -1; j.o0 = 0; j.i0 = 0;
+        j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.col_off = 0; j.i_limit = 256; j.scale = 1.0f; j.bias = 1;
+      } else {
       for (int ot = 0; ot < 2; ++ot)
         for (int itl = 0; itl < 2; ++itl) {
           WgJob& j = jobs.j[jobs.n++];
@@ -407,10 +630,22 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
           j.ldx = 256; j.ldy = 256; j.x1_rows = n; j.y1_rows = -1; j.o0 = 128 * ot; j.i0 = 128 * itl;
           j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.col_off = 0; j.i_limit = 256; j.scale = 1.0f; j.bias = itl == 0;
         }
+      }
+    }
+    if (big.n > 0) {
+      rc = wgrad256_run(big, n_rows, n, fx, out, PIR_K_WGRAD, stream_);
+      if (rc != PIR_OK) return rc;
     }
     hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
                        g_sdf ? g_sdf + base : nullptr, n, row0);
-    rc = wgrad_run(jobs, n_rows, n, fx, row0, out, PIR_K_WGRAD, stream_);
+    if (jobs.n > 0) {
+      rc = wgrad_run(jobs, n_rows, n, fx, row0, out, PIR_K_WGRAD, stream_);
+    } else {      // row 0 of dW8 / db8[0] alone: the reduction kernel's extra block
+      WgJobs none;
+      none.n = 0;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(16), dim3(256), 0, stream, none, 1, fx.slabs, fx.bias_slabs, row0, out);
+      rc = pir_check_launch();
+    }
     if (rc != PIR_OK) return rc;
     rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
