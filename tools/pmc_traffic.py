@@ -15,7 +15,7 @@ import os
 import sys
 
 NAMES = {"sdf_eval_kernel<2>": "sdf_eval_kernel(get_all)", "sdf_eval_kernel<0>": "sdf_eval_kernel(forward)",
-         "pir::bwd_sweep_kernel": "bwd_sweep_kernel", "wgrad_kernel": "wgrad_kernel",
+         "pir::bwd_sweep_kernel": "bwd_sweep_kernel", "wgrad_kernel": "wgrad_kernel", "wgrad256_kernel": "wgrad256_kernel",
          "mlp_eval_kernel": "mlp_eval_kernel", "mlp_bwd_sweep_kernel": "mlp_bwd_sweep_kernel"}
 SUFFIX = os.environ.get("PMC_SUFFIX", "")     # e.g. "(diffuse)": one entry per profiled network
 
@@ -42,7 +42,7 @@ def main():
     for k in fetch:
         if SUFFIX and not k.startswith("mlp_"):
             continue
-        n = min(pts, 131072.0) if k in ("bwd_sweep_kernel", "wgrad_kernel") else pts
+        n = min(pts, float(os.environ.get("PMC_CHUNK", "262144"))) if k in ("bwd_sweep_kernel", "wgrad_kernel", "wgrad256_kernel") else pts
         out[k + SUFFIX] = {"points_per_launch": n, "fetch_bytes_corrected": 2.0 * fetch[k], "write_bytes": write.get(k, 0.0),
                   "hbm_bytes_per_point": (2.0 * fetch[k] + write.get(k, 0.0)) / n}
         print(k + SUFFIX, out[k + SUFFIX], "dispatches", nf[k])
