@@ -421,7 +421,7 @@ def render_fn(interior_mask, mats, tables, ray_o, ray_d, points, normals, geo_f,
     n = interior_mask.shape[0]
 
     def pad(v, width):
-        buf = torch.zeros(n, width) if width > 0 else torch.zeros(n)
+        buf = torch.zeros(n, width, dtype=v.dtype) if width > 0 else torch.zeros(n, dtype=v.dtype)
         if interior_mask.any():
             buf[interior_mask] = v
         return buf

@@ -129,10 +129,12 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     load_first_block<kTPW>(pk.mats, kFwd[0], kTPW * w, pre);
     // ------------------------------------------------------------------ FT sweep: activations + tangents
 #pragma nounroll
-    for (int l = 0; l < 8; ++l) {
-      zero_acc(acc);
-      gemm_phase_pre<kTPW, false, true>(pk.mats, kFwd[l], kTPW * w, lds, l == 0 ? kActKB : 0, acc, pre, true,
-                                        l < 7 ? kFwd[l + 1] : kRev[7]);
+    for (int ph = 0; ph < kFwdPhases; ++ph) {
+      if (fwd_phase_first(ph)) zero_acc(acc);
+      gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre, true,
+                                        ph < kFwdPhases - 1 ? kFwdPh[ph + 1] : kRev[7]);
+      if (!fwd_phase_last(ph)) continue;
+      const int l = fwd_phase_layer(ph);
       __syncthreads();
       PIR_PRIO_HI();
       const float* bias = pk.vecs + kVecBias + 256 * l;

@@ -37,6 +37,21 @@ constexpr int kHidden = 256;
 constexpr int kSkipKeep = 217;     // outputs of lin3 (256 - 39)
 constexpr int kPeDim = 39;
 constexpr int kFeat = 256;         // feature outputs of lin8 (d_out - 1)
+// lin4's input is [a3 (217) | PE (39)] / sqrt2 (src/network.py:90-91).  lin3 is padded to 256 outputs, so round 1 ran
+// lin4 over the whole activation image plus the PE region: 128 + 20 k-steps, 16 of them (k-blocks 28..31) all zero.
+// Now lin4 is two back-to-back GEMM phases into the same accumulators -- k-blocks 0..27 of the activation image
+// (features 0..223), then the 5 k-blocks of the PE region: the same products in the same order (bit-identical
+// results), 33 k-blocks instead of 37 (forward 30.15 -> 29.71 ms per 4 M points).  -DPIR_SKIP_TWOPHASE=0 = round 1.
+// Measured and not kept: carrying the 39 encoding rows of lin4^T in its dead rows 217..255 and parking them from
+// the epilogue instead of the separate two-tile product of waves 0 and 1 -- that product is only 0.7 % of the
+// reverse sweep (the co-resident workgroup fills the matrix pipe meanwhile) and the parking stores cost more:
+// get_all 62.2 -> 64.9 ms per 4 M points, bwd_sweep 35.8 -> 36.4 ms per 1 M.
+#ifndef PIR_SKIP_TWOPHASE
+#define PIR_SKIP_TWOPHASE 1
+#endif
+constexpr bool kSkipTwoPhase = PIR_SKIP_TWOPHASE != 0;
+constexpr int kSkipNatKB = kSkipTwoPhase ? 28 : kActKB;   // k-blocks of lin4's input taken from the activation image
+constexpr int kF4KB = kSkipNatKB + kPeKB;
 
 // ---- packed weight stream ---------------------------------------------------------------
 // A product is stored as f32x4 [kb][tile][lane]; element c of the f32x4 is k-step 4*kb+c.
@@ -49,8 +64,10 @@ constexpr Prod kF0 = {0, kPeKB, 8};
 constexpr Prod kF1 = {kF0.off + prod_size(kF0.nkb, 8), kActKB, 8};
 constexpr Prod kF2 = {kF1.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kF3 = {kF2.off + prod_size(kActKB, 8), kActKB, 8};
-constexpr Prod kF4 = {kF3.off + prod_size(kActKB, 8), kSetKB, 8};
-constexpr Prod kF5 = {kF4.off + prod_size(kSetKB, 8), kActKB, 8};
+constexpr Prod kF4 = {kF3.off + prod_size(kActKB, 8), kF4KB, 8};
+constexpr Prod kF4a = {kF4.off, kSkipNatKB, 8};                          // ... its activation part
+constexpr Prod kF4b = {kF4.off + prod_size(kSkipNatKB, 8), kPeKB, 8};    // ... its encoding part
+constexpr Prod kF5 = {kF4.off + prod_size(kF4KB, 8), kActKB, 8};
 constexpr Prod kF6 = {kF5.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kF7 = {kF6.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kF8 = {kF7.off + prod_size(kActKB, 8), kActKB, 8};       // feature rows 1..256 of lin8

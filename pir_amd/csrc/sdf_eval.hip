@@ -12,8 +12,8 @@ struct PackDesc {
   int transposed;         // 0: A rows = output neurons; 1: A rows = input features (W^T)
   int out_kind;           // 0 natural, 1 PE tile
   int out_limit, out_off;
-  int in_kind;            // 0 natural, 1 PE only, 2 natural (128 k-steps) then PE
-  int in_limit, in_off, in_pe_off;
+  int in_kind;            // 0 natural, 1 PE only, 2 natural (in_nat k-steps) then PE
+  int in_limit, in_off, in_pe_off, in_nat;
   float scale;
 };
 
@@ -51,11 +51,11 @@ __global__ void pack_kernel(PackArgs a, float* __restrict__ mats, float* __restr
     }
     // k-side index
     int ki = -1;
-    if (d.in_kind == 0 || (d.in_kind == 2 && s < 128)) {
+    if (d.in_kind == 0 || (d.in_kind == 2 && s < d.in_nat)) {
       const int f = nat_feature(s, h);
       if (f < d.in_limit) ki = f + d.in_off;
     } else {
-      const int col = pe_column(d.in_kind == 2 ? s - 128 : s, h);
+      const int col = pe_column(d.in_kind == 2 ? s - d.in_nat : s, h);
       if (col >= 0) ki = col + d.in_pe_off;
     }
     float v = 0.f;
@@ -129,7 +129,7 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
 static void fill_desc(PackArgs& a) {
   const float is2 = 0.70710678118654752440f;
   auto D = [&](int i, Prod p, int src, int tr, int ok, int ol, int oo, int ik, int il, int io, int ipo, float sc) {
-    a.d[i] = PackDesc{p.off, p.nkb, p.ntiles, src, tr, ok, ol, oo, ik, il, io, ipo, sc};
+    a.d[i] = PackDesc{p.off, p.nkb, p.ntiles, src, tr, ok, ol, oo, ik, il, io, ipo, 4 * kSkipNatKB, sc};
   };
   D(0, kF0, 0, 0, 0, 256, 0, 1, 0, 0, 0, 1.f);
   D(1, kF1, 1, 0, 0, 256, 0, 0, 256, 0, 0, 1.f);

@@ -10,6 +10,14 @@
 namespace pir {
 
 __device__ constexpr Prod kFwd[9] = {kF0, kF1, kF2, kF3, kF4, kF5, kF6, kF7, kF8};
+// GEMM phases of the hidden layers: with kSkipTwoPhase lin4 is two phases (activation part, encoding part)
+constexpr int kFwdPhases = kSkipTwoPhase ? 9 : 8;
+__device__ constexpr Prod kFwdPh[9] = {kF0, kF1, kF2, kF3, kSkipTwoPhase ? kF4a : kF4, kSkipTwoPhase ? kF4b : kF5,
+                                       kSkipTwoPhase ? kF5 : kF6, kSkipTwoPhase ? kF6 : kF7, kF7};
+__device__ __forceinline__ int fwd_phase_layer(int ph) { return kSkipTwoPhase && ph > 4 ? ph - 1 : ph; }
+__device__ __forceinline__ bool fwd_phase_first(int ph) { return !(kSkipTwoPhase && ph == 5); }   // starts a layer
+__device__ __forceinline__ bool fwd_phase_last(int ph) { return !(kSkipTwoPhase && ph == 4); }    // ends a layer
+__device__ __forceinline__ int fwd_phase_kb0(int ph) { return ph == 0 || (kSkipTwoPhase && ph == 5) ? kActKB : 0; }
 __device__ constexpr Prod kRev[9] = {kR0P, kR1, kR2, kR3, kR4, kR5, kR6, kR7, kR8};
 
 constexpr int kScratchLayerF4 = kSets * 8 * 4 * 64;       // f32x4 per layer image: [set][T][g][lane]
@@ -26,10 +34,12 @@ __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, fl
   f32x4 pre[kTPW];
   load_first_block<kTPW>(pk.mats, kFwd[0], kTPW * w, pre);
 #pragma nounroll
-  for (int l = 0; l < 8; ++l) {
-    zero_acc(acc);
-    const Prod p = kFwd[l];
-    gemm_phase_pre<kTPW, false, true>(pk.mats, p, kTPW * w, lds, l == 0 ? kActKB : 0, acc, pre, l < 7, kFwd[l < 7 ? l + 1 : l]);
+  for (int ph = 0; ph < kFwdPhases; ++ph) {
+    if (fwd_phase_first(ph)) zero_acc(acc);
+    gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre,
+                                      ph < kFwdPhases - 1, kFwdPh[ph < kFwdPhases - 1 ? ph + 1 : ph]);
+    if (!fwd_phase_last(ph)) continue;
+    const int l = fwd_phase_layer(ph);
     __syncthreads();   // every read of the previous activations is done
     PIR_PRIO_HI();
     epilogue_softplus<STORE>(lds, acc, pk.vecs + kVecBias + 256 * l, scratch + (size_t)l * kScratchLayerF4);
