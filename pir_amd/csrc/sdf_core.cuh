@@ -135,6 +135,24 @@ struct Lds {
 };
 static_assert(sizeof(Lds) <= 80 * 1024, "two workgroups per CU must fit in 160 KB");
 
+// ---- in-kernel stamps (diagnosis build -DPIR_STAMPS only; tools/dev/stamps.py reads them) ------------------------
+// Lane 0 of every wave adds the shader cycles since its previous stamp to one of 8 LDS counters: 1 GEMM phase,
+// 2 barrier after it, 3 epilogue, 4 barrier after the epilogue, 5 everything else of a tile, 6 reverse epilogue, 7 reverse GEMM phase (1 and 3 = forward).
+#ifdef PIR_STAMPS
+__shared__ long long g_stamp[kWaves][8];
+__device__ __forceinline__ void pir_stamp(int i) {
+  if (lane_id() == 0) {
+    const long long t = (long long)__builtin_amdgcn_s_memtime();
+    long long* s = g_stamp[wave_id()];
+    s[i] += t - s[0];
+    s[0] = t;
+  }
+}
+#define PIR_STAMP(i) pir_stamp(i)
+#else
+#define PIR_STAMP(i)
+#endif
+
 // ---- the GEMM phase ---------------------------------------------------------------------------
 // acc[set][t] += W[tile 4*wave+t (or given first tile)] x act[set], over nkb k-blocks starting at LDS
 // k-block lds_kb0.  NT tiles for this wave starting at global tile `tile0`.

@@ -92,6 +92,12 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   const long ntiles = (M + kWgPts - 1) / kWgPts;
   f32x4* scratch = kNormal ? scratch_all + (size_t)blockIdx.x * kScratchWgF4 : nullptr;
+#ifdef PIR_STAMPS
+  if (lane == 0) {
+    for (int i = 1; i < 8; ++i) g_stamp[w][i] = 0;
+    g_stamp[w][0] = (long long)__builtin_amdgcn_s_memtime();
+  }
+#endif
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long base = tile * kWgPts;
     const long P = base + 32 * (w & 1) + j;
@@ -123,7 +129,14 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
       }
     }
     __syncthreads();
+    PIR_STAMP(5);
   }
+#ifdef PIR_STAMPS
+  if (kNormal && lane == 0) {
+    long long* out = reinterpret_cast<long long*>(scratch + 8 * (size_t)kScratchLayerF4) + 8 * w;
+    for (int i = 0; i < 8; ++i) out[i] = g_stamp[w][i];
+  }
+#endif
 }
 
 static void fill_desc(PackArgs& a) {

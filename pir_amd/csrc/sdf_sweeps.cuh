@@ -21,7 +21,11 @@ __device__ __forceinline__ int fwd_phase_kb0(int ph) { return ph == 0 || (kSkipT
 __device__ constexpr Prod kRev[9] = {kR0P, kR1, kR2, kR3, kR4, kR5, kR6, kR7, kR8};
 
 constexpr int kScratchLayerF4 = kSets * 8 * 4 * 64;       // f32x4 per layer image: [set][T][g][lane]
+#ifdef PIR_STAMPS
+constexpr int kScratchWgF4 = 8 * kScratchLayerF4 + kWaves * 4;   // a0..a7 + 8 stamp counters per wave
+#else
 constexpr int kScratchWgF4 = 8 * kScratchLayerF4;         // a0..a7
+#endif
 constexpr size_t kScratchWgBytes = (size_t)kScratchWgF4 * sizeof(f32x4);
 
 template <bool STORE>
@@ -38,13 +42,17 @@ __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, fl
     if (fwd_phase_first(ph)) zero_acc(acc);
     gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre,
                                       ph < kFwdPhases - 1, kFwdPh[ph < kFwdPhases - 1 ? ph + 1 : ph]);
+    PIR_STAMP(1);
     if (!fwd_phase_last(ph)) continue;
     const int l = fwd_phase_layer(ph);
     __syncthreads();   // every read of the previous activations is done
+    PIR_STAMP(2);
     PIR_PRIO_HI();
     epilogue_softplus<STORE>(lds, acc, pk.vecs + kVecBias + 256 * l, scratch + (size_t)l * kScratchLayerF4);
     PIR_PRIO_LO();
+    PIR_STAMP(3);
     __syncthreads();
+    PIR_STAMP(4);
   }
 }
 
@@ -198,11 +206,15 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
     zero_acc(acc);
     gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[l], kTPW * w, lds, 0, acc, pre, l >= 2, kRev[l >= 2 ? l - 1 : l]);
     if (l == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+    PIR_STAMP(7);
     __syncthreads();
+    PIR_STAMP(2);
     PIR_PRIO_HI();
     epilogue_mul_dact(lds, acc, scratch + (size_t)(l - 1) * kScratchLayerF4);
     PIR_PRIO_LO();
+    PIR_STAMP(6);
     __syncthreads();
+    PIR_STAMP(4);
   }
   if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
   float n[kSets][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
