@@ -310,6 +310,48 @@ class Camera(object):
                 cropped[key] = img[ul_row:ul_row + trgt_H, ul_col:ul_col + trgt_W]
         return Camera(trgt_W, trgt_H, K, self.W2C.clone()), cropped
 
+    def resize(self, factor, image=None):
+        """raytracer.py:385-402: a camera with both image sides scaled by factor < 1 (intrinsics rows scaled
+        accordingly) and, optionally, the image area-averaged to that size."""
+        assert factor < 1.0
+        trgt_H, trgt_W = int(self.H * factor), int(self.W * factor)
+        K = self.K.clone()
+        K[0, :3] *= trgt_W / self.W
+        K[1, :3] *= trgt_H / self.H
+        camera = Camera(trgt_W, trgt_H, K, self.W2C.clone())
+        if image is not None:
+            image = _resize_area(image, trgt_W, trgt_H).to(image.device)
+        return camera, image
+
+
+def _area_weights(src, dst, device):
+    """[dst, src] weights of an area-averaging downscale (OpenCV's INTER_AREA table, computeResizeAreaTab: the share
+    of every source cell that a destination cell of width src/dst covers, normalised by the cell width)."""
+    scale = src / dst
+    w = torch.zeros(dst, src, dtype=torch.float64)
+    for d in range(dst):
+        f1 = d * scale
+        f2 = f1 + scale
+        cell = min(scale, src - f1)
+        s1, s2 = int(np.ceil(f1)), min(int(np.floor(f2)), src - 1)
+        s1 = min(s1, s2)
+        if s1 - f1 > 1e-3:
+            w[d, s1 - 1] = (s1 - f1) / cell
+        w[d, s1:s2] = 1.0 / cell
+        if f2 - s2 > 1e-3:
+            w[d, s2] = min(min(f2 - s2, 1.0), cell) / cell
+    return w.float().to(device)
+
+
+def _resize_area(image, trgt_W, trgt_H):
+    """cv2.resize(image, (trgt_W, trgt_H), interpolation=cv2.INTER_AREA) for an [H, W] or [H, W, C] float image
+    without cv2 (not installed here: parity with OpenCV is unpinned; for integer factors this is the plain box mean)."""
+    H, W = image.shape[0], image.shape[1]
+    img = image.detach().float()
+    ry, rx = _area_weights(H, trgt_H, img.device), _area_weights(W, trgt_W, img.device)
+    out = torch.einsum("ih,hw...->iw...", ry, img)
+    return torch.einsum("jw,iw...->ij...", rx, out).contiguous()
+
 
 def _camera_rays_hip(camera, uv, is_pixel_grid):
     dev = camera.device

@@ -80,9 +80,18 @@ class _GgxFn(torch.autograd.Function):
                 None, None, None)
 
 
-def _smith_g1(c, a):
-    root = a * (torch.sqrt(1.0 - c * c) / (c + 1e-10))
+def smithG1(cosTheta, alpha):
+    """Smith shadowing term of one direction (renderer_ggx.py:8-12)."""
+    root = alpha * (torch.sqrt(1.0 - cosTheta * cosTheta) / (cosTheta + 1e-10))
     return 2.0 / (1.0 + torch.hypot(root, torch.ones_like(root)))
+
+
+def G_fn(dot_wi_n, dot_wo_n, alpha):
+    """renderer_ggx.py:14-15."""
+    return smithG1(dot_wi_n, alpha) * smithG1(dot_wo_n, alpha)
+
+
+_smith_g1 = smithG1
 
 
 class GGXColocatedRenderer(nn.Module):

@@ -351,3 +351,29 @@ def test_full_size_material_networks_match_reference_on_cpu():
             yo = O.dino_mlp(layers, cfg, pts) if name == "dino_network" else \
                 O.rendering_mlp(layers, cfg, pts, nrm, -nrm if name == "diffuse_albedo_network" else None, geo, dino)
         assert rel_err(yo, d[f"{name}.out"]) < 1e-5, name
+
+
+def test_camera_resize_and_ggx_helpers():
+    """Camera.resize (raytracer.py:385-402): intrinsics rows scale with the sides, the image is area-averaged (box mean
+    for an integer factor; rows of the area table sum to 1 otherwise).  smithG1 / G_fn (renderer_ggx.py:8-15)."""
+    import math
+    from pir_amd.renderer.raytracer import Camera, _area_weights
+    from pir_amd.renderer.renderer_ggx import smithG1, G_fn
+    K = torch.eye(4)
+    K[0, 0] = K[1, 1] = 160.0
+    K[0, 2], K[1, 2] = 40.0, 30.0
+    cam = Camera(80, 60, K, torch.eye(4))
+    img = torch.rand(60, 80, 3)
+    small, im = cam.resize(0.25, img)
+    assert (small.W, small.H) == (20, 15)
+    assert torch.allclose(small.K[0, :3], K[0, :3] * 0.25) and torch.allclose(small.K[1, :3], K[1, :3] * 0.25)
+    box = torch.nn.functional.avg_pool2d(img.permute(2, 0, 1)[None], 4)[0].permute(1, 2, 0)
+    assert torch.allclose(im, box, atol=1e-6)
+    w = _area_weights(80, 24, "cpu")                       # factor 0.3: fractional cells
+    assert torch.allclose(w.sum(dim=1), torch.ones(24), atol=1e-6) and float(w.min()) >= 0.0
+    _, im2 = cam.resize(0.3, img[..., 0])
+    assert im2.shape == (18, 24) and abs(float(im2.mean() - img[..., 0].mean())) < 1e-3
+    c, a = torch.tensor([0.5]), torch.tensor([0.3])
+    g1 = 2.0 / (1.0 + math.hypot(0.3 * math.sqrt(1 - 0.25) / (0.5 + 1e-10), 1.0))
+    assert abs(float(smithG1(c, a)) - g1) < 1e-6
+    assert abs(float(G_fn(c, c, a)) - g1 * g1) < 1e-6
