@@ -25,3 +25,32 @@ class FrequencyEncoding:
 def get_embedder(multires, input_dims=3):
     enc = FrequencyEncoding(multires, input_dims)
     return enc, enc.out_dim
+
+
+class Embedder:
+    """The general encoder behind get_embedder (src/models/embedder.py:6-41), for callers that build one from keyword
+    settings: include_input, input_dims, max_freq_log2, num_freqs, log_sampling (bands 2^linspace(0, max) or
+    linspace(1, 2^max)), periodic_fns.  Output order: [x] then, per band, one block per periodic function."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        self.create_embedding_fn()
+
+    def create_embedding_fn(self):
+        kw = self.kwargs
+        n, top = int(kw["num_freqs"]), float(kw["max_freq_log2"])
+        if kw["log_sampling"]:
+            bands = 2.0 ** torch.linspace(0.0, top, n)
+        else:
+            bands = torch.linspace(1.0, 2.0 ** top, n)
+        self.freq_bands = [float(b) for b in bands]
+        self.periodic_fns = list(kw["periodic_fns"])
+        self.include_input = bool(kw["include_input"])
+        self.out_dim = int(kw["input_dims"]) * (int(self.include_input) + n * len(self.periodic_fns))
+
+    def embed(self, inputs):
+        parts = [inputs] if self.include_input else []
+        for f in self.freq_bands:
+            scaled = inputs * f
+            parts.extend(fn(scaled) for fn in self.periodic_fns)
+        return torch.cat(parts, -1)

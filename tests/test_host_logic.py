@@ -377,3 +377,18 @@ def test_camera_resize_and_ggx_helpers():
     g1 = 2.0 / (1.0 + math.hypot(0.3 * math.sqrt(1 - 0.25) / (0.5 + 1e-10), 1.0))
     assert abs(float(smithG1(c, a)) - g1) < 1e-6
     assert abs(float(G_fn(c, c, a)) - g1 * g1) < 1e-6
+
+
+def test_embedder_class_matches_get_embedder():
+    """Embedder (src/models/embedder.py:6-41) built with get_embedder's settings gives get_embedder's encoding; the
+    linear band spacing and include_input=False variants have the documented sizes."""
+    from pir_amd.models.embedder import Embedder, get_embedder
+    x = torch.rand(7, 3) * 2 - 1
+    e = Embedder(include_input=True, input_dims=3, max_freq_log2=5, num_freqs=6, log_sampling=True,
+                 periodic_fns=[torch.sin, torch.cos])
+    fn, dim = get_embedder(6, 3)
+    assert e.out_dim == dim == 39 and torch.equal(e.embed(x), fn(x))
+    lin = Embedder(include_input=False, input_dims=2, max_freq_log2=3, num_freqs=4, log_sampling=False,
+                   periodic_fns=[torch.sin])
+    assert lin.out_dim == 8 and lin.freq_bands[0] == 1.0 and lin.freq_bands[-1] == 8.0
+    assert lin.embed(torch.rand(4, 2)).shape == (4, 8)
