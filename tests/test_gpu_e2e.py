@@ -192,3 +192,31 @@ def test_visibility_bake_800_properties_and_subsample_vs_oracle():
     ref = O.light_visibility(side.cpu(), pts, layers, inv_s.cpu(), n_samples=256, is_training=False)
     got = vis.reshape(-1)[idx].cpu()
     assert (got - ref).abs().max().item() < 2e-4, (got - ref).abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("thr,iters,n_steps", [(2.0e-4, 8, 64), (1.0e-5, 24, 200), (5.0e-5, 0, 33)])
+def test_trace_non_default_settings_vs_oracle(thr, iters, n_steps):
+    """RayTracer(sdf_threshold, sphere_tracing_iters, n_steps) away from the defaults (raytracer.py:39-54): fewer / more
+    sphere-tracing iterations, no sphere tracing at all, coarser / finer / odd sampler grids, looser / tighter
+    thresholds (the bisection bound follows the threshold) -- 128 x 128 view against the CPU oracle with the same
+    settings, grazing rays included."""
+    from oracle import pir_oracle as O
+    from pir_amd import scene
+    from pir_amd.renderer.raytracer import RayTracer, raytrace_camera
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    cam = scene.make_camera(128, 128, device="cuda")
+    tr = RayTracer(sdf_threshold=thr, sphere_tracing_iters=iters, n_steps=n_steps)
+    res = raytrace_camera(cam, net, tr)
+    tr.check_status()
+    layers = O.mlp_layers(state_from_npz(load_golden("sdf_full_bumpy_weights.npz")))
+    ocam = O.CameraRays(128, 128, cam.K.cpu(), cam.W2C.cpu())
+    ref = O.raytrace_camera(ocam, layers, O.Tracer(sdf_threshold=thr, sphere_tracing_iters=iters, n_steps=n_steps))
+    m, rm = res["convergent_mask"].cpu(), ref["convergent_mask"]
+    assert (m != rm).sum().item() <= 1, (m != rm).sum().item()
+    both = m & rm
+    assert both.float().mean().item() > 0.2
+    err = (res["distance"].cpu() - ref["distance"])[both].abs().max().item()
+    assert err <= 1e-4 * ref["distance"][both].max().item() + 2 * thr, err
+    perr = (res["points"].cpu() - ref["points"])[both].abs().max().item()
+    assert perr <= 1e-4 + 2 * thr, perr
