@@ -261,6 +261,15 @@ def main():
             roofline["traffic_unit"] = "bytes/launch (PMC bytes/point x points/launch)"
     except (OSError, ValueError, KeyError):
         pass
+    # matrix-pipe busy share and effective clock of the same kernel from the committed PMC pass
+    # (profiles/r02_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; tools/profile_mfma.sh)
+    try:
+        mu = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")))
+        if roofline and names[dom] in mu:
+            roofline["mfma_busy_share_pmc"] = mu[names[dom]]["mfma_busy_share_of_simd_cycles"]
+            roofline["effective_clock_GHz_pmc"] = mu[names[dom]]["effective_clock_GHz"]
+    except (OSError, ValueError, KeyError):
+        pass
     breakdown = {names[i]: {"launches": int(launches[i]), "ms_per_step": round(total_ms[i] / args.steps, 3)}
                  for i in range(nk) if launches[i]}
 
