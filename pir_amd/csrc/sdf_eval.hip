@@ -135,6 +135,7 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
   if (kNormal && lane == 0) {
     long long* out = reinterpret_cast<long long*>(scratch + 8 * (size_t)kScratchLayerF4) + 8 * w;
     for (int i = 0; i < 8; ++i) out[i] = g_stamp[w][i];
+    out[0] = (long long)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // raw HW_ID of this wave
   }
 #endif
 }

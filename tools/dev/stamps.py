@@ -22,3 +22,14 @@ print("workgroups", nwg, "cycles per wave: mean %.3e min %.3e max %.3e" % (tot.m
 for w in range(4):
     print("wave", w, {names[i]: round((raw[:, w, i].sum() / tot[:, w].sum()).item(), 4) for i in range(1, 8)})
 print("all  ", {names[i]: round((raw[:, :, i].sum() / tot.sum()).item(), 4) for i in range(1, 8)})
+
+hw = buf.view(nwg, per)[:, per - 4 * 64:].contiguous().view(torch.int64).view(nwg, 4, 8)[:, :, 0]
+import collections
+print("HW_ID wave slot (bits 3:0) histogram:", sorted(collections.Counter((hw & 15).flatten().tolist()).items()))
+print("SIMD id (bits 5:4) by wave index:", [sorted(collections.Counter(((hw[:, w] >> 4) & 3).tolist()).items()) for w in range(4)])
+cu = ((hw >> 8) & 15) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5)
+pairs = collections.defaultdict(list)
+for b in range(nwg):
+    pairs[int(cu[b, 0])].append((b, int(hw[b, 0] & 15)))
+print("workgroups per (se, sh, cu) key (XCC not included):", sorted(collections.Counter(len(v) for v in pairs.values()).items()))
+print("examples:", list(pairs.items())[:4])
