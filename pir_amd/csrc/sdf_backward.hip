@@ -131,6 +131,7 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
 #pragma nounroll
     for (int ph = 0; ph < kFwdPhases; ++ph) {
       if (fwd_phase_first(ph)) zero_acc(acc);
+      // (plain two-tile phases here: the padding-tile skip of fwd_gemm_phase costs this kernel 15 spilled registers)
       gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre, true,
                                         ph < kFwdPhases - 1 ? kFwdPh[ph + 1] : kRev[7]);
       if (!fwd_phase_last(ph)) continue;

@@ -78,8 +78,10 @@ constexpr Prod kR6 = {kR7.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kR5 = {kR6.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kR4 = {kR5.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kR4P = {kR4.off + prod_size(kActKB, 8), kActKB, 2};      // PE rows of lin4^T
-constexpr Prod kR3 = {kR4P.off + prod_size(kActKB, 2), kActKB, 8};
-constexpr Prod kR2 = {kR3.off + prod_size(kActKB, 8), kActKB, 8};
+// lin3^T: k = the 217 outputs of lin3 -> k-blocks 0..27 (round 1 also ran the four all-zero k-blocks 28..31)
+constexpr int kR3KB = kSkipTwoPhase ? kSkipNatKB : kActKB;
+constexpr Prod kR3 = {kR4P.off + prod_size(kActKB, 2), kR3KB, 8};
+constexpr Prod kR2 = {kR3.off + prod_size(kR3KB, 8), kActKB, 8};
 constexpr Prod kR1 = {kR2.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kR0P = {kR1.off + prod_size(kActKB, 8), kActKB, 2};      // PE rows of lin0^T
 constexpr int kPackedF4 = kR0P.off + prod_size(kActKB, 2);              // total f32x4 count

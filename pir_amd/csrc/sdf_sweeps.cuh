@@ -20,6 +20,28 @@ __device__ __forceinline__ bool fwd_phase_last(int ph) { return !(kSkipTwoPhase 
 __device__ __forceinline__ int fwd_phase_kb0(int ph) { return ph == 0 || (kSkipTwoPhase && ph == 5) ? kActKB : 0; }
 __device__ constexpr Prod kRev[9] = {kR0P, kR1, kR2, kR3, kR4, kR5, kR6, kR7, kR8};
 
+// One forward GEMM phase of this wave's tiles.  lin3 has 217 outputs, so tile 7 (rows 224..255: the second tile of
+// the last wave) is all padding: its MFMAs are not issued and its accumulators stay 0, which is what the zero weight
+// rows produced (round 1 executed them).  The matrix pipe is shared with the co-resident workgroup, so the saving
+// shows although the other waves of this workgroup still run two tiles.
+__device__ __forceinline__ void fwd_gemm_phase(const SdfPacked& pk, int ph, const Lds& lds, f32x16 (&acc)[kSets][kTPW],
+                                               f32x4 (&pre)[kTPW], bool prefetch_next, Prod next) {
+  const int w = wave_id();
+  if (kSkipTwoPhase && kTPW == 2 && ph == 3 && w == kWaves - 1) {
+    f32x16 a1[kSets][1];
+    f32x4 p1[1] = {pre[0]};
+#pragma unroll
+    for (int s = 0; s < kSets; ++s) a1[s][0] = acc[s][0];
+    gemm_phase_pre<1, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), a1, p1, prefetch_next, next);
+#pragma unroll
+    for (int s = 0; s < kSets; ++s) acc[s][0] = a1[s][0];
+    pre[0] = p1[0];
+    if (prefetch_next) pre[kTPW - 1] = pk.mats[next.off + (size_t)(kTPW * w + kTPW - 1) * kTileKB + lane_id()];
+  } else {
+    gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre, prefetch_next, next);
+  }
+}
+
 constexpr int kScratchLayerF4 = kSets * 8 * 4 * 64;       // f32x4 per layer image: [set][T][g][lane]
 #ifdef PIR_STAMPS
 constexpr int kScratchWgF4 = 8 * kScratchLayerF4 + kWaves * 4;   // a0..a7 + 8 stamp counters per wave
@@ -40,8 +62,7 @@ __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, fl
 #pragma nounroll
   for (int ph = 0; ph < kFwdPhases; ++ph) {
     if (fwd_phase_first(ph)) zero_acc(acc);
-    gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre,
-                                      ph < kFwdPhases - 1, kFwdPh[ph < kFwdPhases - 1 ? ph + 1 : ph]);
+    fwd_gemm_phase(pk, ph, lds, acc, pre, ph < kFwdPhases - 1, kFwdPh[ph < kFwdPhases - 1 ? ph + 1 : ph]);
     PIR_STAMP(1);
     if (!fwd_phase_last(ph)) continue;
     const int l = fwd_phase_layer(ph);
