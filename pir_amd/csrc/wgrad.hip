@@ -349,25 +349,28 @@ wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float
   const int nprod = jb.X2 ? 2 : 1;
   const int nsteps = (it1 - it0) * nprod;
   TileRegs2 tx, ty;
-  auto fetch = [&](int step) {
+  auto fetch_into = [&](int step, TileRegs2& fx_, TileRegs2& fy_) {
     const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts;
-    load_tile2(tx, prod ? jb.X2 : jb.X1, 256, row0, prod ? -1 : jb.x1_rows);
-    load_tile2(ty, prod ? jb.Y2 : jb.Y1, jb.ldy, row0, prod ? -1 : jb.y1_rows);
+    load_tile2(fx_, prod ? jb.X2 : jb.X1, 256, row0, prod ? -1 : jb.x1_rows);
+    load_tile2(fy_, prod ? jb.Y2 : jb.Y1, jb.ldy, row0, prod ? -1 : jb.y1_rows);
   };
-  if (nsteps > 0) fetch(0);
-  for (int step = 0; step < nsteps; ++step) {
-    __syncthreads();
-    store_tile2(Xs, tx);
-    store_tile2(Ys, ty);
-    __syncthreads();
-    if (step + 1 < nsteps) fetch(step + 1);
-    __builtin_amdgcn_sched_barrier(0);
+  auto bias_rows = [&](int step) {
     if (jb.bias && step % nprod == 0) {
       const int col = threadIdx.x & 255, half = threadIdx.x >> 8;
 #pragma unroll
       for (int r = 0; r < 16; ++r) bsum += Xs[16 * half + r][col];
     }
-    if (jb.ldy >= kW2Tile) {
+  };
+  if (jb.ldy >= kW2Tile) {
+    if (nsteps > 0) fetch_into(0, tx, ty);
+    for (int step = 0; step < nsteps; ++step) {
+      __syncthreads();
+      store_tile2(Xs, tx);
+      store_tile2(Ys, ty);
+      __syncthreads();
+      if (step + 1 < nsteps) fetch_into(step + 1, tx, ty);
+      __builtin_amdgcn_sched_barrier(0);
+      bias_rows(step);
 #pragma unroll
       for (int s2 = 0; s2 < kWgKPts / 2; ++s2) {
         const float a0 = Xs[2 * s2 + kh][64 * wr + lo], a1 = Xs[2 * s2 + kh][64 * wr + 32 + lo];
@@ -380,7 +383,21 @@ wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float
           acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[t], acc[1][t], 0, 0, 0);
         }
       }
-    } else if (jb.ldy < kW2Tile) {     // the 64-wide encoding operand of layer 0: every wave takes 32 output rows
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+    // The 64-wide encoding operand of layer 0: every wave takes 32 output rows x 64 columns, a quarter of the MFMAs
+    // of a full-width step (1.7 us), which is less than the latency of the operand fetch.  Two register stages keep
+    // the fetch two steps ahead (the accumulators of this path leave the registers free).
+    TileRegs2 ux, uy;
+    auto narrow_step = [&](int step, TileRegs2& fx_, TileRegs2& fy_) {
+      __syncthreads();
+      store_tile2(Xs, fx_);
+      store_tile2(Ys, fy_);
+      __syncthreads();
+      if (step + 2 < nsteps) fetch_into(step + 2, fx_, fy_);
+      __builtin_amdgcn_sched_barrier(0);
+      bias_rows(step);
 #pragma unroll
       for (int s2 = 0; s2 < kWgKPts / 2; ++s2) {
         const float a0 = Xs[2 * s2 + kh][32 * wv + lo];
@@ -390,8 +407,14 @@ wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float
           acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nsteps > 0) fetch_into(0, tx, ty);
+    if (nsteps > 1) fetch_into(1, ux, uy);
+    for (int step = 0; step < nsteps; step += 2) {
+      narrow_step(step, tx, ty);
+      if (step + 1 < nsteps) narrow_step(step + 1, ux, uy);
     }
-    __builtin_amdgcn_sched_barrier(0);
   }
   float* slab = slabs + (size_t)blockIdx.x * kW2Tile * kW2Tile;
   if (jb.ldy >= kW2Tile) {
@@ -456,13 +479,16 @@ int wgrad256_run(const WgJobs& jobs, int n_rows, int n_points, const WgFixed& fx
   hipStream_t stream = (hipStream_t)stream_;
   if (jobs.n < 1 || jobs.n > 10 || n_rows < kWgKPts || (n_rows % kWgKPts)) return PIR_ERR_ARG;
   // One resident workgroup per CU (64 KB LDS, 512 threads at 256 registers).  Work units per 32 points: 20 for a
-  // job with two products over full-width operands, 12 for the 64-wide layer-0 operand (a quarter of the MFMAs, but
-  // its steps are bound by the latency of the operand fetch: 4.6 us against 7.9 us measured), half for a single
-  // product (the feature rows of lin8); every job gets K slices in proportion, as many as fill one round of the CUs,
-  // so that all workgroups finish together.
+  // job with two products over full-width operands, 10 for the 64-wide layer-0 operand (a quarter of the MFMAs, but
+  // its steps stay bound by the operand fetch even with the fetch two steps ahead; measured optimum of 3..6), half
+  // for a single product (the feature rows of lin8); every job gets K slices in proportion, as many as fill one
+  // round of the CUs, so that all workgroups finish together.
   int cost[10], total = 0;
   for (int j = 0; j < jobs.n; ++j) {
-    cost[j] = (jobs.j[j].ldy < kW2Tile ? 6 : 10) * (jobs.j[j].X2 ? 2 : 1);
+#ifndef PIR_W2_NARROW_COST
+#define PIR_W2_NARROW_COST 5
+#endif
+    cost[j] = (jobs.j[j].ldy < kW2Tile ? PIR_W2_NARROW_COST : 10) * (jobs.j[j].X2 ? 2 : 1);
     total += cost[j];
   }
   const int steps = n_rows / kWgKPts;
