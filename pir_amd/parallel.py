@@ -81,35 +81,52 @@ class FlatGradBucket:
             off += p.numel()
         self.present = self.flat[n:]
         self.n = n
+        self._patterns = {}                   # device copies of the presence flags, one per pattern seen
 
     def all_reduce(self, average=False):
         """Copy .grad into the bucket, all-reduce once, copy back.  average=False: the gradient of a SUM loss over all
-        rays of all ranks (what one process rendering every ray would compute)."""
-        flags = []
-        for p, v in zip(self.params, self.views):
-            if p.grad is None:
+        rays of all ranks (what one process rendering every ray would compute).
+
+        The collective runs whenever a process group exists (also with ONE rank, where it is the identity: that is how
+        the RCCL branch is exercised on a one-GPU box).  Host traffic per call: none in the steady state.  The presence
+        flags are kept on the device per pattern of None gradients (uploaded once per pattern) and the reduced flags
+        are read back only while some parameter has no gradient on this rank (then another rank may have one)."""
+        flags = tuple(p.grad is not None for p in self.params)
+        grads = [p.grad for p, f in zip(self.params, flags) if f]
+        if grads:
+            torch._foreach_copy_([v for v, f in zip(self.views, flags) if f], grads)
+        for v, f in zip(self.views, flags):
+            if not f:
                 v.zero_()
-                flags.append(0.0)
-            else:
-                v.copy_(p.grad)
-                flags.append(1.0)
-        self.present.copy_(torch.tensor(flags, dtype=torch.float32), non_blocking=True)
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if world > 1:
+        pattern = self._patterns.get(flags)
+        if pattern is None:                   # first time this set of None gradients is seen: one small upload
+            pattern = torch.tensor([float(f) for f in flags], dtype=torch.float32).to(self.flat.device)
+            self._patterns[flags] = pattern
+        self.present.copy_(pattern)           # device-to-device
+        grouped = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if grouped else 1
+        if grouped:
             if self.flat.is_cuda and dist.get_backend() == "gloo":   # CPU-staged rehearsal of the RCCL path
                 host = self.flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
                 self.flat.copy_(host)
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            if average:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)     # RCCL when the backend is 'nccl'
+            if average and world > 1:
                 self.flat[:self.n].div_(world)
-        have = (self.present > 0).tolist() if world > 1 else [f > 0 for f in flags]
+        if world > 1 and not all(flags):
+            have = (self.present > 0).tolist()   # another rank may hold a gradient this rank lacks: one read-back
+        else:
+            have = flags
+        dst, src = [], []
         for p, v, h in zip(self.params, self.views, have):
             if not h:
                 continue                      # no rank produced a gradient: leave p.grad = None
             if p.grad is None:
                 p.grad = v.clone()
             else:
-                p.grad.copy_(v)
+                dst.append(p.grad)
+                src.append(v)
+        if dst:
+            torch._foreach_copy_(dst, src)
         return self.flat[:self.n]

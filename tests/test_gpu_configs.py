@@ -200,3 +200,68 @@ def test_bench_two_ranks_one_device_rehearsal():
         assert out["n_gpus"] == 2 and out["value"] > 0
         assert out["scaling"] == ("weak" if shard == "views" else "strong")
         assert out["config"]["views"] == (2 if shard == "views" else 1)
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: the script itself launches two ranks (fresh child
+    processes; the launcher never touches the GPU) and relays rank 0's JSON line with n_gpus == 2.  A WORLD_SIZE that
+    contradicts --gpus is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--res", "64",
+           "--backend", "gloo", "--one-device"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["views"] == 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--res", "64"],
+                         capture_output=True, text=True, env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"),
+                         timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+def test_rccl_all_reduce_branch_world_size_one():
+    """FlatGradBucket.all_reduce through RCCL (backend 'nccl', a one-rank group on cuda:0: the collective is the
+    identity but librccl is loaded, a communicator is built and the device-buffer branch executes): the gradients
+    are bit-identical to the bucket-less run, None gradients stay None."""
+    import torch.distributed as dist
+    from pir_amd import scene
+    from pir_amd.parallel import FlatGradBucket
+    from pir_amd.render_fn import make_render_fn
+    from pir_amd.renderer.raytracer import RayTracer, render_camera
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    render_fn = make_render_fn(GGXColocatedRenderer(use_cuda=True))
+    inv_s = torch.full((1, 1), scene.INV_S, device="cuda")
+
+    def grads():
+        sdf, mats, dino = scene.build_networks(seed=0, device="cuda")
+        params = [p for mod in [sdf] + [mats[k] for k in sorted(mats)] for p in mod.parameters()]
+        cam = scene.make_camera(48, 48, device="cuda")
+        lp = cam.get_light_pos(mats["point_light_network"].offset)
+        out = render_camera(cam, sdf, RayTracer(), mats, dino, render_fn, fill_holes=False, handle_edges=False,
+                            inv_s=inv_s, render_visibility=True, light_pos=lp, indirect_warmup=True, is_training=True)
+        scene.step_loss(out).backward()
+        return params
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29561", world_size=1, rank=0,
+                            device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        params = grads()
+        plain = [None if p.grad is None else p.grad.clone() for p in params]     # the bucket-less gradients
+        bucket = FlatGradBucket(params)
+        for _ in range(2):                      # twice: the second call reuses the cached flag pattern
+            flat = bucket.all_reduce(average=False)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    n_none = 0
+    for p, g in zip(params, plain):
+        if g is None:
+            assert p.grad is None
+            n_none += 1
+        else:
+            assert torch.equal(p.grad, g)
+    assert float(flat.abs().sum()) > 0
+    print("RCCL one-rank all-reduce: bit-identical gradients,", n_none, "parameters without a gradient stay None")
