@@ -153,6 +153,21 @@ int pir_shade_inputs_backward(long P, const float* points, const float* normal, 
                               const float* g_distance, const float* g_points, float* g_normal, float* g_sdf,
                               float* g_origin, void* stream);
 
+/* ---- frequency encoding (src/models/embedder.py:20-41, get_embedder(multires, input_dims): every network input
+ *      [x | sin(2^k x) | cos(2^k x)]_{k < L}, blocks of D columns; row width D (1 + 2 L)) -------------------------- */
+
+/* out[P, D(1+2L)] = E(x) for x[P, D].  Embedder.embed / the embed_fn returned by get_embedder (embedder.py:38-41). */
+int pir_embed_forward(long P, int D, int L, const float* x, float* out, void* stream);
+/* g_x[P, D] = the vector-Jacobian product of E at x with g_out[P, D(1+2L)] (autograd's backward of the encoding). */
+int pir_embed_backward(long P, int D, int L, const float* x, const float* g_out, float* g_x, void* stream);
+/* The two halves of the backward OF that backward, taken when the material smoothness loss differentiates the
+ * networks w.r.t. the surface point with create_graph=True (render_surface.py:40-48) and loss.backward() then
+ * differentiates once more: out[P, D(1+2L)] = J_E(x) u (gradient w.r.t. g_out, for u[P, D]) ... */
+int pir_embed_tangent(long P, int D, int L, const float* x, const float* u, float* out, void* stream);
+/* ... and g_x[P, D] = u * d/dx <g_out, dE/dx> (gradient w.r.t. x). */
+int pir_embed_second(long P, int D, int L, const float* x, const float* g_out, const float* u, float* g_x,
+                     void* stream);
+
 /* ---- material / feature-field MLPs (src/network.py:146-267 RenderingNetwork, :382-467 DINONetwork, :295-367
  *      BlendNetwork): ReLU MLPs with 256-wide hidden layers, the input optionally concatenated again at one skip
  *      layer ([h | x] / sqrt 2, :237-238), linear output layer ------------------------------------------------ */

@@ -74,6 +74,10 @@ def _declare(L):
     L.pir_shade_inputs_forward.argtypes = [lg, vp, vp, vp, i32, vp, vp, vp, vp]
     L.pir_shade_inputs_backward.restype = i32
     L.pir_shade_inputs_backward.argtypes = [lg, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name, n_ptr in (("pir_embed_forward", 2), ("pir_embed_backward", 3), ("pir_embed_tangent", 3), ("pir_embed_second", 4)):
+        fn = getattr(L, name)
+        fn.restype = i32
+        fn.argtypes = [lg, i32, i32] + [vp] * n_ptr + [vp]
     L.pir_mlp_product_floats.restype = sz
     L.pir_mlp_product_floats.argtypes = [i32]
     L.pir_mlp_pack_product.restype = i32

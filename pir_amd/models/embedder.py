@@ -5,6 +5,8 @@
 """
 import torch
 
+FUSED = True    # A/B switch: False = the eager expression below on the GPU as well
+
 
 class FrequencyEncoding:
     def __init__(self, n_freqs: int, input_dims: int = 3):
@@ -14,6 +16,10 @@ class FrequencyEncoding:
         self.bands = [float(2.0 ** k) for k in range(self.n_freqs)]
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        if x.is_cuda and FUSED:
+            from .. import embed_hip
+            if embed_hip.supported(x, self.n_freqs, self.input_dims):
+                return embed_hip.embed(x, self.n_freqs)     # one kernel each way (pir_embed_*), twice differentiable
         parts = [x]
         for f in self.bands:
             xf = x * f

@@ -1,0 +1,50 @@
+"""fp64 adjudication of the composite fixtures (tracer in the loop): e2e_tile.npz, next_rows.npz, train_step.npz.
+
+tests/golden/composite_fp64.npz holds the same reference code run on the same weights and inputs under
+torch.set_default_dtype(float64) (tools/gen_golden_fp64.py).  Every tensor is judged element-wise as in
+full800_util: `ok` within 1e-4 of the fp32 reference; `ok-fp64` no farther from the fp64 run than 2x the fp32
+reference is on that tensor; `ok-group` no farther than the fp32 reference is on the worst tensor of the same
+network's gradients (and < 1e-3 from fp64); anything else FAILs."""
+import numpy as np
+
+from conftest import load_golden
+from full800_util import judge, verdicts, print_report
+
+_c64 = None
+
+
+def c64():
+    global _c64
+    if _c64 is None:
+        _c64 = load_golden("composite_fp64.npz")
+    return _c64
+
+
+class Adjudicator:
+    def __init__(self, title, prefix):
+        self.title, self.prefix, self.report = title, prefix, []
+
+    def add(self, name, got, ref32, group=None):
+        got = np.asarray(got, np.float64)
+        ref32 = np.asarray(ref32, np.float64)
+        ref64 = np.asarray(c64()[self.prefix + name], np.float64)
+        if got.size == ref32.size == ref64.size == 1:
+            got, ref32, ref64 = got.reshape(1), ref32.reshape(1), ref64.reshape(1)
+        assert got.shape == ref32.shape == ref64.shape, (name, got.shape, ref32.shape, ref64.shape)
+        judge(name, got, ref32, ref64, self.report, group=group)
+
+    def add_grads(self, fixture, fixture_prefix, net_name, named_params):
+        for k, p in named_params:
+            ref = fixture[f"{fixture_prefix}g.{net_name}.{k}"]
+            g = p.grad.detach().cpu().numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+            self.add(f"g.{net_name}.{k}", g if g.shape == ref.shape else g[::8], ref)
+
+    def finish(self):
+        ok = verdicts(self.report)
+        print_report(self.report, self.title)
+        counts = {}
+        for row in self.report:
+            counts[row[4]] = counts.get(row[4], 0) + 1
+        print(f"  {self.title}: {len(self.report)} tensors -> {counts}")
+        assert ok, [r[0] for r in self.report if r[4] == "FAIL"]
+        return counts

@@ -26,7 +26,7 @@ def build(device):
     return d, net.to(device), {k: v.to(device) for k, v in mats.items()}, dino.to(device)
 
 
-def run(device, tol, grad_tol, point_tol, exact_edges=True):
+def run(device, tol, grad_tol, point_tol, exact_edges=True, adjudicate=False):
     """Returns nothing; asserts every stage against the fixture.  `tol` bounds images (max-normalised), `grad_tol`
     parameter gradients, `point_tol` 3-D positions."""
     from pir_amd.render_fn import make_render_fn
@@ -104,3 +104,19 @@ def run(device, tol, grad_tol, point_tol, exact_edges=True):
             ref = d[f"g.{nm}.{k}"]
             g = npy(p.grad) if p.grad is not None else np.zeros(p.shape, np.float32)
             assert rel_err(g if g.shape == ref.shape else g[::8], ref) < grad_tol, (nm, k)
+    if adjudicate and np.array_equal(lit, lit_ref) and np.array_equal(npy(res["edge_mask"]), d["edge.edge_mask"]):
+        from composite_util import Adjudicator
+        A = Adjudicator(f"edges + indirect bounce on {device} vs next_rows.npz", "nx.")
+        A.add("final.color", npy(res["color"]), d["final.color"])
+        A.add("final.normal", npy(res["normal"]), d["final.normal"])
+        A.add("final.vis", npy(res["vis"]), d["final.vis"])
+        A.add("indirect_color", npy(res["indirect_color"]), d["indirect_color"])
+        A.add("indirect_blend_coef", npy(res["indirect_blend_coef"]), d["indirect_blend_coef"])
+        A.add("edge_pos_neg_normal", npy(res["edge_pos_neg_normal"]), d["edge_pos_neg_normal"])
+        A.add("loss", np.array([loss.item()]), np.array([float(d["loss"])]))
+        A.add("g_light", npy(pl.light.grad).reshape(()), d["g_light"], group="g.point_light")
+        A.add("g_offset", npy(pl.light_offset.weight.grad), d["g_offset"], group="g.point_light")
+        A.add_grads(d, "", "sdf", net.named_parameters())
+        for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "blend_network"):
+            A.add_grads(d, "", nm, mats[nm].named_parameters())
+        return A.finish()

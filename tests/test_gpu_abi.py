@@ -170,3 +170,43 @@ def test_shade_inputs_abi_edge_cases():
                         indirect_warmup=True, is_training=True)
     assert not res["convergent_mask"].any()
     assert res["color"].abs().max().item() == 0 and res["vis"].abs().max().item() == 0 and res["normal"].shape == (16, 16, 3)
+
+
+@pytest.mark.parametrize("D,L", [(3, 10), (3, 6), (3, 4), (1, 6), (3, 0)])
+def test_embed_kernels_match_the_eager_encoding_to_second_order(D, L):
+    """pir_embed_forward / _backward / _tangent / _second against the reference's eager expression
+    (src/models/embedder.py:20-41) under autograd: values bit-identical (same sinf / cosf), first derivatives and the
+    derivative of the first derivative (the smoothness loss's create_graph path) within 1e-6."""
+    from pir_amd import _lib
+    from pir_amd.models import embedder
+    enc = embedder.FrequencyEncoding(L, D)
+    g = torch.Generator().manual_seed(100 * D + L)
+    x0 = ((torch.rand(1537, D, generator=g) * 2 - 1) * 1.3).cuda()
+    c0 = torch.randn(1537, enc.out_dim, generator=g).cuda()
+    c2 = torch.randn(1537, enc.out_dim, generator=g).cuda()
+    w = torch.randn(1537, D, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        embedder.FUSED = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            c = c0.clone().requires_grad_(True)
+            out = enc(x)
+            (gx,) = torch.autograd.grad((out * c).sum(), x, create_graph=True)
+            ((gx * w).sum() + (out * c2).sum()).backward()
+            res.append((out.detach(), gx.detach(), x.grad.clone(), c.grad.clone()))
+        finally:
+            embedder.FUSED = True
+    (o1, g1, xg1, cg1), (o0, g0, xg0, cg0) = res
+    assert torch.equal(o1, o0)
+    for a, b, name in ((g1, g0, "first derivative"), (xg1, xg0, "d/dx of it"), (cg1, cg0, "d/dg of it")):
+        err = ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+        assert err < 1e-6, (name, err)
+    # 3-D leading shape and a non-contiguous view go through the same kernels
+    x3 = x0[:1536].reshape(4, 384, D)
+    assert torch.equal(enc(x3), o1[:1536].reshape(4, 384, -1))
+    # raw C ABI: zero points is a no-op, bad sizes are refused
+    L_ = _lib.lib()
+    assert L_.pir_embed_forward(0, D, L, None, None, None) == 0
+    assert L_.pir_embed_forward(4, 0, L, _lib.ptr(x0), _lib.ptr(o1), None) == 1
+    assert L_.pir_embed_backward(4, D, 17, _lib.ptr(x0), _lib.ptr(c0), _lib.ptr(w), None) == 1

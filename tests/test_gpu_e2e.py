@@ -64,17 +64,21 @@ def test_render_camera_tile_matches_reference(tag):
     loss.backward()
     if use_vis:
         mostly_close("vis")
-        assert rel_err(pl.light_offset.weight.grad.cpu().numpy(), d["offset.g_offset"]) < 2e-5
-    assert abs(pl.light.grad.item() - float(d[f"{tag}.g_light"])) < 2e-4 * abs(float(d[f"{tag}.g_light"]))
-    for k, p in net.named_parameters():
-        ref = d[f"{tag}.g.sdf.{k}"]
-        assert rel_err(grad_np(p, ref.shape), ref) < 3e-4, k
+    # every tensor element-wise against the fp32 reference, with the fp64 run of the same reference code as the arbiter
+    # where fp32 round-off (the tracer's 5e-5 stopping band times the 2^9-frequency encodings) exceeds 1e-4
+    from composite_util import Adjudicator
+    A = Adjudicator(f"render_camera tile ({tag}) on cuda vs e2e_tile.npz", f"e2e.{tag}.")
+    npy = lambda t: t.detach().cpu().numpy()  # noqa: E731
+    for key in ("color", "normal", "diffuse_albedo", "specular_roughness", "depth") + (("vis",) if use_vis else ()):
+        A.add(key, npy(res[key]), d[f"{tag}.{key}"])
+    A.add("loss", np.array([loss.item()]), np.array([float(d[f"{tag}.loss"])]))
+    A.add("g_light", npy(pl.light.grad).reshape(()), d[f"{tag}.g_light"], group="g.point_light")
+    if use_vis:
+        A.add("g_offset", npy(pl.light_offset.weight.grad), d["offset.g_offset"], group="g.point_light")
+    A.add_grads(d, f"{tag}.", "sdf", net.named_parameters())
     for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
-        for k, p in mats[nm].named_parameters():
-            ref = d[f"{tag}.g.{nm}.{k}"]
-            g = p.grad.cpu().numpy() if p.grad is not None else np.zeros(p.shape, np.float32)
-            g = g if g.shape == ref.shape else g[::8]
-            assert rel_err(g, ref) < 1e-3, (nm, k)
+        A.add_grads(d, f"{tag}.", nm, mats[nm].named_parameters())
+    A.finish()
 
 
 def test_trace_800_properties_and_subsample_vs_oracle():

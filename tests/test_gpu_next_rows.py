@@ -10,7 +10,7 @@ def test_edges_and_indirect_lighting_match_reference():
     import next_rows_util
     # Tolerances as in test_gpu_e2e: 97 % of the pixels within 1e-4 (max-normalised), the rest (tracer threshold
     # sensitivity amplified by the 2^9-frequency encodings) within 2e-3; hit points within 2.5e-4.
-    next_rows_util.run("cuda", tol=1e-4, grad_tol=5e-4, point_tol=5e-5, exact_edges=False)   # achieved: 2.0e-4
+    next_rows_util.run("cuda", tol=1e-4, grad_tol=5e-4, point_tol=5e-5, exact_edges=False, adjudicate=True)
 
 
 def test_full_render_camera_with_edges_and_indirect_runs_and_is_deterministic():
@@ -52,7 +52,7 @@ def test_training_step_matches_reference():
     # Material-network gradients get a wider bound: the albedo MLP encodes the hit point with frequencies up to 2^9,
     # so the tracer's legitimate 1e-4 differences in a few hit points (the CPU run of the same
     # code meets 3e-4 on every gradient) move them by a few 1e-3.
-    train_step_util.run("cuda", tol=1e-4, grad_tol=1.5e-3, exact=False, mat_grad_tol=1e-2)   # achieved: 7.5e-4 / 8.9e-3
+    train_step_util.run("cuda", tol=1e-4, grad_tol=1.5e-3, exact=False, mat_grad_tol=1e-2, adjudicate=True)
 
 
 def test_visibility_cache_round_trip(tmp_path):

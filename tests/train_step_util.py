@@ -43,7 +43,7 @@ def build_state(device):
     return d, state
 
 
-def run(device, tol, grad_tol, exact=True, mat_grad_tol=None):
+def run(device, tol, grad_tol, exact=True, mat_grad_tol=None, adjudicate=False):
     from pir_amd import train
     d, state = build_state(device)
     np.random.seed(int(d["np_seed"]))
@@ -83,4 +83,17 @@ def run(device, tol, grad_tol, exact=True, mat_grad_tol=None):
     assert np.abs(npy(sdf.lin8.bias) - d["after.sdf.lin8.bias"]).max() < 2e-6
     assert np.abs(npy(sdf.lin2.weight_g) - d["after.sdf.lin2.weight_g"]).max() < 2e-6
     assert np.array_equal(npy(nets["diffuse_albedo_network"].lin0.bias), d["after.diffuse.lin0.bias"])
+    if adjudicate:
+        # element-wise, per tensor, with the fp64 run of the same reference loop as the arbiter (composite_fp64.npz)
+        from composite_util import Adjudicator
+        A = Adjudicator(f"training step on {device} vs train_step.npz", "ts.")
+        A.add("out.color", npy(out["results"]["color"]), d["out.color"])
+        for k in ("loss", "img_loss", "img_l1_loss", "img_l2_loss", "img_ssim_loss", "eik_loss", "smoothness_loss"):
+            A.add("out." + k, np.array([out[k]]), np.array([float(d["out." + k])]), group="out.losses")
+        A.add("g_light", npy(pl.light.grad).reshape(()), d["g_light"], group="g.point_light")
+        A.add("g_offset", npy(pl.light_offset.weight.grad), d["g_offset"], group="g.point_light")
+        A.add_grads(d, "", "sdf", sdf.named_parameters())
+        for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "blend_network"):
+            A.add_grads(d, "", nm, nets[nm].named_parameters())
+        out["adjudication"] = A.finish()
     return out

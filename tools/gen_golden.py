@@ -532,6 +532,9 @@ def main():
         ts["out.K_crop"] = _np(ns3["camera_crop"].K)
         ts["out.mask"], ts["out.edge_mask"] = _np(ns3["convergent_mask"]), _np(ns3["results"]["edge_mask"])
         ts["out.color"] = _np(ns3["results"]["color"])
+        # hit points / depth of the rendered crop (round 3): lets the GPU test count the pixels whose sphere trace
+        # stopped one iteration apart from the reference's (the only discontinuity in the path)
+        ts["out.points"], ts["out.depth"] = _np(ns3["results"]["points"]), _np(ns3["results"]["depth"])
         ts.update({"g.sdf." + k: v for k, v in grads_subsample(t_sdf.named_parameters()).items()})
         for nm in list(MAT) + ["blend_network"]:
             ts.update({f"g.{nm}." + k: v for k, v in grads_subsample(t_cnd[nm].named_parameters()).items()})
@@ -546,6 +549,102 @@ def main():
         print("train step: loss", ts["out.loss"], "hits", int(ts["out.mask"].sum()), "edges", int(ts["out.edge_mask"].sum()),
               "smooth", ts["out.smoothness_loss"], "rough", ts["out.roughrange_loss"], "idx", ts["out.idx"])
         save(os.path.join(out_dir, "train_step.npz"), **ts)
+
+    # K = 5 consecutive iterations of the same loop text (round 3): Adam state, the optimizer
+    # schedule across a phase change, weight re-packing after every step.  global_step 11998..12002 with
+    # render_visibility_step = 12000: the first two iterations light the scene from the camera and step EVERY
+    # optimizer (render_surface.py:697-699), the last three render shadows and step only the SDF and the point light
+    # (:687-696).  Each iteration is one exec of the loop text with start_step / num_iters bracketing one step;
+    # networks, optimizers and both random generators carry over.
+    if not only or "train_traj.npz" in only:
+        K = 5
+        targs = Namespace(is_metal=False, smoothness_weight=1e-4, num_iters=0, roughness_warmup_step=2000,
+                          indirect_warmup_step=10000, render_visibility=True, render_visibility_step=12000,
+                          render_brdf=False, patch_size=32, gamma_pred=False, eik_weight=0.1, ssim_weight=1.0,
+                          roughrange_weight=0.1)
+        ns2 = dict(torch=torch, nn=nn, F=F, np=np, dino_dimension=384, args=targs, ggx_renderer_modified=ggx)
+        exec("\n".join(lines[39:176]), ns2)
+        t_sdf = SDFNetwork(**SDF_FULL)
+        t_sdf.load_state_dict(net_edge.state_dict())
+        t_cnd = {k: RenderingNetwork(**v) for k, v in MAT.items()}
+        t_cnd["point_light_network"] = PointLightNetwork(enable_offset=True)
+        t_cnd["blend_network"] = BlendNetwork(**BLEND)
+        for k in MAT:
+            t_cnd[k].load_state_dict(cnd[k].state_dict())
+        t_cnd["blend_network"].load_state_dict(cnd["blend_network"].state_dict())
+        t_cnd["point_light_network"].set_light(135.0)
+        t_cnd["point_light_network"].light_offset.weight.data = torch.tensor([[0.2, 0.1, 0.05]])
+        t_dino = DINONetwork(**DINO)
+        t_dino.load_state_dict(dino_net.state_dict())
+        g = torch.Generator().manual_seed(62)
+        gt_images = torch.rand(2, 64, 64, 3, generator=g)
+        grad_images = [torch.rand(64, 64, generator=g) for _ in range(2)]
+        cams = [standard_camera(rt.Camera, 64, 64, roty=-0.6), standard_camera(rt.Camera, 64, 64, roty=0.9)]
+        sdf_opt = torch.optim.Adam(t_sdf.parameters(), lr=1e-5)
+        plp = [{"params": [t_cnd["point_light_network"].light], "lr": 2e-5},
+               {"params": list(t_cnd["point_light_network"].light_offset.parameters()), "lr": 1e-4}]
+        copt = {k: (torch.optim.Adam(plp) if k == "point_light_network" else torch.optim.Adam(v.parameters(), lr=1e-4))
+                for k, v in t_cnd.items()}
+        dino_opt = torch.optim.Adam(t_dino.parameters(), lr=1e-3)
+        tq = types.ModuleType("tqdm")
+        tq.tqdm = lambda it, **k: it
+        ns3 = dict(torch=torch, np=np, tqdm=tq, args=targs, start_step=0, sdf_optimizer=sdf_opt,
+                   color_optimizer_dict=copt, dino_optimizer=dino_opt, gt_images=gt_images, grad_images=grad_images,
+                   cameras=cams, color_network_dict=t_cnd, sdf_network=t_sdf, raytracer=tracer, dino_network=t_dino,
+                   render_fn=ns2["render_fn"], render_camera=rt.render_camera, fill_holes=False, handle_edges=True,
+                   is_training=True, inv_s=inv_s, pyramidl2_loss_fn=pyr, ssim_loss_fn=il.ssim_loss_fn,
+                   ssim_weight=targs.ssim_weight, smoothness_weight=targs.smoothness_weight,
+                   roughrange_weight=targs.roughrange_weight, eik_weight=targs.eik_weight)
+        watch = {"sdf.lin0.weight_v": t_sdf.lin0.weight_v, "sdf.lin4.weight_g": t_sdf.lin4.weight_g,
+                 "sdf.lin8.bias": t_sdf.lin8.bias, "sdf.lin8.weight_v": t_sdf.lin8.weight_v,
+                 "diffuse.lin0.bias": t_cnd["diffuse_albedo_network"].lin0.bias,
+                 "diffuse.lin8.weight_v": t_cnd["diffuse_albedo_network"].lin8.weight_v,
+                 "specular.lin2.weight_g": t_cnd["specular_albedo_network"].lin2.weight_g,
+                 "roughness.lin4.bias": t_cnd["specular_roughness_network"].lin4.bias,
+                 "blend.lin0.bias": t_cnd["blend_network"].lin0.bias,
+                 "light": t_cnd["point_light_network"].light,
+                 "offset": t_cnd["point_light_network"].light_offset.weight}
+        tj = dict(gt_images=_np(gt_images), grad_images=np.stack([_np(x) for x in grad_images]),
+                  K=np.stack([_np(c.K) for c in cams]), W2C=np.stack([_np(c.W2C) for c in cams]), inv_s=_np(inv_s),
+                  np_seed=81, torch_seed=82, first_step=11998, n_steps=K, render_visibility_step=12000)
+        tj.update(state_to_np("sdf.", t_sdf))
+        tj.update(state_to_np("mat.blend_network.", t_cnd["blend_network"]))
+        tj.update({"before." + k: _np(v) for k, v in watch.items()})
+        np.random.seed(81)
+        torch.manual_seed(82)
+        loop_text = "\n".join(lines[544:699])
+        terms = ("loss", "img_loss", "img_l1_loss", "img_l2_loss", "img_ssim_loss", "eik_loss", "roughrange_loss",
+                 "smoothness_loss")
+        per_step = {k: [] for k in terms}
+        idxs, k_crops, hits, edges, shadow = [], [], [], [], []
+        # the eikonal samples each iteration will draw: replay the generator on a copy of its state
+        eik = []
+        for i in range(K):
+            step = 11998 + i
+            ns3["start_step"], targs.num_iters = step - 1, step + 1
+            st = torch.get_rng_state()
+            exec(loop_text, ns3)
+            after = torch.get_rng_state()
+            torch.set_rng_state(st)
+            eik.append(_np(torch.empty(32 * 32 // 2, 3).float().uniform_(-1.0, 1.0)))
+            torch.set_rng_state(after)
+            assert ns3["global_step"] == step
+            for k in terms:
+                per_step[k].append(float(ns3[k].reshape(-1)[0]) if torch.is_tensor(ns3[k]) else float(ns3[k]))
+            idxs.append(int(ns3["idx"]))
+            k_crops.append(_np(ns3["camera_crop"].K))
+            hits.append(int(ns3["convergent_mask"].sum()))
+            edges.append(int(ns3["results"]["edge_mask"].sum()))
+            shadow.append(bool(ns3["render_shadow"]))
+            tj[f"mask.{i}"] = _np(ns3["convergent_mask"])
+            tj[f"edge_mask.{i}"] = _np(ns3["results"]["edge_mask"])
+            tj.update({f"after{i}." + k: _np(v) for k, v in watch.items()})
+        tj["eik_points"] = np.stack(eik)
+        tj.update({"steps." + k: np.asarray(v, np.float64) for k, v in per_step.items()})
+        tj["steps.idx"], tj["steps.K_crop"] = np.asarray(idxs), np.stack(k_crops)
+        tj["steps.hits"], tj["steps.edges"], tj["steps.render_shadow"] = np.asarray(hits), np.asarray(edges), np.asarray(shadow)
+        print("train trajectory: losses", per_step["loss"], "hits", hits, "edges", edges, "shadow", shadow, "idx", idxs)
+        save(os.path.join(out_dir, "train_traj.npz"), **tj)
 
     # known-answer GGX cases of SURVEY.md Appendix A are asserted directly in the tests.
     tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
