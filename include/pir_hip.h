@@ -153,6 +153,16 @@ int pir_shade_inputs_backward(long P, const float* points, const float* normal, 
                               const float* g_distance, const float* g_points, float* g_normal, float* g_sdf,
                               float* g_origin, void* stream);
 
+/* ---- IRON edge sampling: the surface walk of locate_edge_points (src/renderer/raytracer.py:497-560) ------------- */
+
+/* Walks points[n,3] (in place) along the surface towards the silhouette seen from cam_o[3] (device pointer): per step
+ * get_all at the point, stop when |n_hat . view_hat| <= dot_threshold (found[i] = 1), else move by
+ * step_size * (normalize(n_hat - view_hat / dot) - sdf n_hat); at most max_step steps (points still walking after
+ * the test of step max_step keep found[i] = 0, as in the reference loop :521-541).  One launch, no host sync.
+ * scratch: as for pir_sdf_get_all. */
+int pir_edge_walk(const void* packed, long n, float* points, const float* cam_o, int max_step, float step_size,
+                  float dot_threshold, unsigned char* found, void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- frequency encoding (src/models/embedder.py:20-41, get_embedder(multires, input_dims): every network input
  *      [x | sin(2^k x) | cos(2^k x)]_{k < L}, blocks of D columns; row width D (1 + 2 L)) -------------------------- */
 

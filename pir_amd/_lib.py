@@ -78,6 +78,8 @@ def _declare(L):
         fn = getattr(L, name)
         fn.restype = i32
         fn.argtypes = [lg, i32, i32] + [vp] * n_ptr + [vp]
+    L.pir_edge_walk.restype = i32
+    L.pir_edge_walk.argtypes = [vp, lg, vp, vp, i32, f32, f32, vp, vp, sz, vp]
     L.pir_mlp_product_floats.restype = sz
     L.pir_mlp_product_floats.argtypes = [i32]
     L.pir_mlp_pack_product.restype = i32

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpir_hip.so")
-SOURCES = ["sdf_eval.hip", "trace.hip", "ggx.hip", "sdf_backward.hip", "wgrad.hip", "visibility.hip", "mlp.hip", "shade_inputs.hip", "embed.hip", "prof.hip"]
+SOURCES = ["sdf_eval.hip", "trace.hip", "ggx.hip", "sdf_backward.hip", "wgrad.hip", "visibility.hip", "mlp.hip", "shade_inputs.hip", "embed.hip", "edge_walk.hip", "prof.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment"]
 
 

@@ -71,4 +71,5 @@ def embed(x, n_freqs):
     flat = x.reshape(-1, x.shape[-1])
     if not flat.is_contiguous():
         flat = flat.contiguous()
-    return _Embed.apply(flat, int(n_freqs)).reshape(*lead, -1)
+    width = x.shape[-1] * (1 + 2 * int(n_freqs))
+    return _Embed.apply(flat, int(n_freqs)).reshape(*lead, width)

@@ -283,22 +283,36 @@ class eager_grad:
         return False
 
 
-def _backward_scratch(device, n_hidden):
+def _backward_scratch(device, n_hidden, points):
+    """Backward scratch of the material MLPs: one buffer per (device, stream), sized to the largest call seen there
+    (points rounded up to a power of two, at most BWD_CHUNK_POINTS).  The SDF backward's buffer of the same stream is
+    used instead when it is large enough (the two never run concurrently on one stream)."""
     skey = _lib.stream_key(device)
-    key = skey + (n_hidden,)
-    buf = _bwd_scratch_cache.get(key)
-    if buf is None:
-        # the SDF backward's buffer is larger than any material network needs: share it when it exists
-        from . import sdf_hip
-        need = _lib.lib().pir_mlp_backward_scratch_bytes(n_hidden, BWD_CHUNK_POINTS)
-        for k, b in sdf_hip._bwd_scratch_cache.items():
-            if k[:2] == skey and b.numel() >= need:      # same device AND same stream only
-                buf = b
-                break
-        if buf is None:
-            buf = torch.empty(need, dtype=torch.uint8, device=device)
-        _bwd_scratch_cache[key] = buf
+    want = min(BWD_CHUNK_POINTS, max(4096, 1 << max(0, int(points) - 1).bit_length()))
+    need = _lib.lib().pir_mlp_backward_scratch_bytes(n_hidden, want)
+    from . import sdf_hip
+    shared = sdf_hip._bwd_scratch_cache.get(skey)      # same device AND same stream only
+    if shared is not None and shared.numel() >= need:
+        return shared
+    buf = _bwd_scratch_cache.get(skey)
+    if buf is None or buf.numel() < need:
+        _bwd_scratch_cache.pop(skey, None)
+        buf = None
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _bwd_scratch_cache[skey] = buf
     return buf
+
+
+def free_scratch():
+    """Drop the cached backward scratch buffers of this module (see sdf_hip.free_scratch)."""
+    _bwd_scratch_cache.clear()
+
+
+def _zero_grads(pshapes, dev):
+    """One zero-filled allocation viewed as the per-layer gradient tensors (one fill launch instead of one each)."""
+    sizes = [int(torch.Size(tuple(s)).numel()) for s in pshapes]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    return [p.view(tuple(s)) for p, s in zip(torch.split(flat, sizes), pshapes)]
 
 
 def _run_backward(packed, xp, g_out, need_gx, shapes):
@@ -306,11 +320,11 @@ def _run_backward(packed, xp, g_out, need_gx, shapes):
     dev = xp.device
     nl = packed.n_hidden + 1
     pshapes = packed.padded_shapes(shapes)
-    gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in pshapes[:nl]]
-    gbs = [torch.zeros(s, dtype=torch.float32, device=dev) for s in pshapes[nl:]]
+    zs = _zero_grads(pshapes, dev)
+    gws, gbs = zs[:nl], zs[nl:]
     gx = torch.empty(P, xp.shape[1], dtype=torch.float32, device=dev) if need_gx else None
     g = g_out.detach().reshape(P, packed.n_out).contiguous().float()
-    scratch = _backward_scratch(dev, packed.n_hidden)
+    scratch = _backward_scratch(dev, packed.n_hidden, P)
     wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
     bp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gbs])
     with torch.cuda.device(dev):
@@ -389,8 +403,8 @@ class _MlpBwdFn(torch.autograd.Function):
         P, dev = xp.shape[0], xp.device
         gbar = packed.pad_input(gbar_in.reshape(P, packed.k0))
         ghat = torch.empty(P, packed.n_out, dtype=torch.float32, device=dev)
-        gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in packed.padded_shapes(ctx.shapes)[:nl]]
-        scratch = _backward_scratch(dev, packed.n_hidden)
+        gws = _zero_grads(packed.padded_shapes(ctx.shapes)[:nl], dev)
+        scratch = _backward_scratch(dev, packed.n_hidden, P)
         wp = (ctypes.c_void_p * nl)(*[t.data_ptr() for t in gws])
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().pir_mlp_backward_tangent(

@@ -22,6 +22,7 @@ from .. import _lib
 
 VERBOSE_MODE = False
 dimension = 384
+FUSED_EDGE_WALK = True      # A/B switch: False = one get_all launch + eager ops + a host sync per walk step
 FUSED_SHADE_INPUTS = True   # A/B switch: False = the eager PyTorch expressions of the reference for a9 / shading inputs
 
 
@@ -426,17 +427,9 @@ def unique(x, dim=-1):
     return vals, first.scatter_reduce_(0, inverse, perm, reduce="amin")
 
 
-@torch.no_grad()
-def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_size, dot_threshold,
-                       max_num_rays=200000, mask=None):
-    """Walk on the surface from the depth-edge pixels until the normal is perpendicular to the view direction
-    (raytracer.py:497-615) -> dict(edge_mask [H,W], edge_points [E,3], edge_uv [E,2], edge_pixel_idx [E]).
-    Every step is one `get_all` over the points still walking, i.e. one launch of the fused HIP kernel."""
-    if mask is None:
-        mask = torch.ones_like(walk_start_points[..., 0]).bool()
-    dev = walk_start_points.device
-    cam_o = camera.get_camera_origin()
-    pts = walk_start_points[mask].reshape(-1, 3).detach().clone()
+def _edge_walk_torch(pts, cam_o, sdf_network, max_step, step_size, dot_threshold, max_num_rays):
+    """The walk with eager ops (CPU tensors, SDF architectures the kernels do not cover); updates pts in place."""
+    dev = pts.device
     found = torch.zeros(pts.shape[0], dtype=torch.bool, device=dev)
     for s in range(0, pts.shape[0], max_num_rays):       # the reference walks max_num_rays points at a time
         cur, cur_found = pts[s:s + max_num_rays], found[s:s + max_num_rays]
@@ -457,6 +450,27 @@ def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_si
             step = step - sdf.reshape(-1, 1) * nrm       # stay near the zero level set
             todo = todo[walking]
             cur[todo] += (step_size * step)[walking]
+    return found
+
+
+@torch.no_grad()
+def locate_edge_points(camera, walk_start_points, sdf_network, max_step, step_size, dot_threshold,
+                       max_num_rays=200000, mask=None):
+    """Walk on the surface from the depth-edge pixels until the normal is perpendicular to the view direction
+    (raytracer.py:497-615) -> dict(edge_mask [H,W], edge_points [E,3], edge_uv [E,2], edge_pixel_idx [E]).
+    On the GPU the whole walk of all points is ONE launch (pir_edge_walk)."""
+    if mask is None:
+        mask = torch.ones_like(walk_start_points[..., 0]).bool()
+    dev = walk_start_points.device
+    cam_o = camera.get_camera_origin()
+    pts = walk_start_points[mask].reshape(-1, 3).detach().clone()
+    if pts.is_cuda and FUSED_EDGE_WALK and getattr(sdf_network, "hip_supported", lambda: False)():
+        # the whole walk in one launch (pir_edge_walk); points evolve independently, so the reference's max_num_rays
+        # batching has no effect on the result
+        from .. import sdf_hip
+        pts, found = sdf_hip.edge_walk(sdf_network.packed(), pts, cam_o, max_step, step_size, dot_threshold)
+    else:
+        found = _edge_walk_torch(pts, cam_o, sdf_network, max_step, step_size, dot_threshold, max_num_rays)
     edge_points = pts[found]
     edge_mask = torch.zeros(camera.H, camera.W, dtype=torch.bool, device=dev)
     edge_uv = torch.zeros_like(edge_points[..., :2])

@@ -70,16 +70,32 @@ class PackedSdf:
 
 _bwd_scratch_cache = {}
 BWD_CHUNK_POINTS = 262144   # the C ABI caps a pass at 262 144 points (8.7 GB of scratch); fewer passes = fewer slab reductions
+_BWD_MIN_POINTS = 4096
 
 
-def backward_scratch_for(device, chunk_points: int = None) -> torch.Tensor:
+def backward_scratch_for(device, points: int = None, chunk_points: int = None) -> torch.Tensor:
+    """Scratch of the SDF backward for a call over `points` points: ONE buffer per (device, stream), sized to the
+    largest call seen on that stream (point counts rounded up to a power of two, at most chunk_points = 262 144 points
+    = 8.7 GB; a 128 x 128 training patch needs ~0.3 GB).  A buffer that has to grow replaces the old one.
+    `free_scratch()` drops every cached buffer (e.g. after a transient stream is gone)."""
     chunk_points = chunk_points or BWD_CHUNK_POINTS
-    key = _lib.stream_key(device) + (chunk_points,)
+    want = chunk_points if points is None else min(chunk_points, max(_BWD_MIN_POINTS, 1 << max(0, int(points) - 1).bit_length()))
+    key = _lib.stream_key(device)
     buf = _bwd_scratch_cache.get(key)
-    if buf is None:
-        buf = torch.empty(_lib.lib().pir_sdf_backward_scratch_bytes(chunk_points), dtype=torch.uint8, device=device)
+    need = _lib.lib().pir_sdf_backward_scratch_bytes(want)
+    if buf is None or buf.numel() < need:
+        _bwd_scratch_cache.pop(key, None)
+        buf = None                      # release the smaller buffer before allocating the larger one
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
         _bwd_scratch_cache[key] = buf
     return buf
+
+
+def free_scratch():
+    """Drop every cached scratch / workspace buffer of this module (they are re-created on demand).  Buffers are
+    cached per (device, stream): call this after work on short-lived streams, or to hand the memory back."""
+    _scratch_cache.clear()
+    _bwd_scratch_cache.clear()
 
 
 def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: bool, chunk_points: int = None):
@@ -87,9 +103,13 @@ def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: b
     x = x.detach().reshape(-1, 3).contiguous().float()
     M = x.shape[0]
     dev = x.device
-    gws = [torch.zeros(s, dtype=torch.float32, device=dev) for s in _SDF_SHAPES]
-    gbs = [torch.zeros(s[0], dtype=torch.float32, device=dev) for s in _SDF_SHAPES]
-    gx = torch.zeros(M, 3, dtype=torch.float32, device=dev) if need_gx else None
+    # one zero-filled allocation for all 18 gradient tensors + dL/dx (one fill launch instead of 19)
+    sizes = [a * b for a, b in _SDF_SHAPES] + [a for a, _ in _SDF_SHAPES] + [3 * M if need_gx else 0]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    parts = torch.split(flat, sizes)
+    gws = [parts[i].view(_SDF_SHAPES[i]) for i in range(9)]
+    gbs = list(parts[9:18])
+    gx = parts[18].view(M, 3) if need_gx else None
 
     def prep(g, shape):
         if g is None:
@@ -97,7 +117,7 @@ def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: b
         return g.detach().reshape(shape).contiguous().float()
 
     g_sdf, g_feat, g_normal = prep(g_sdf, (M,)), prep(g_feat, (M, 256)), prep(g_normal, (M, 3))
-    scratch = backward_scratch_for(dev, chunk_points)
+    scratch = backward_scratch_for(dev, M, chunk_points)
     wp = (ctypes.c_void_p * 9)(*[t.data_ptr() for t in gws])
     bp = (ctypes.c_void_p * 9)(*[t.data_ptr() for t in gbs])
     with torch.cuda.device(dev):
@@ -105,3 +125,19 @@ def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: b
             _lib.ptr(packed.buf), _lib.ptr(x), M, _lib.ptr(g_sdf), _lib.ptr(g_feat), _lib.ptr(g_normal), _lib.ptr(gx),
             wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()), "pir_sdf_get_all_backward")
     return gws, gbs, gx
+
+
+def edge_walk(packed: "PackedSdf", points: torch.Tensor, cam_o: torch.Tensor, max_step: int, step_size: float,
+              dot_threshold: float):
+    """The surface walk of locate_edge_points (src/renderer/raytracer.py:497-560) in one launch (pir_edge_walk):
+    -> (final points [n,3], found [n] bool)."""
+    pts = points.detach().reshape(-1, 3).contiguous().float().clone()
+    n = pts.shape[0]
+    found = torch.zeros(n, dtype=torch.uint8, device=pts.device)
+    origin = cam_o.detach().reshape(3).contiguous().float()
+    scratch = scratch_for(pts.device)
+    with torch.cuda.device(pts.device):
+        _lib.check(_lib.lib().pir_edge_walk(_lib.ptr(packed.buf), n, _lib.ptr(pts), _lib.ptr(origin), int(max_step),
+                                            float(step_size), float(dot_threshold), _lib.ptr(found), _lib.ptr(scratch),
+                                            scratch.numel(), _lib.stream_ptr()), "pir_edge_walk")
+    return pts, found.bool()

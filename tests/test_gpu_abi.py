@@ -205,6 +205,7 @@ def test_embed_kernels_match_the_eager_encoding_to_second_order(D, L):
     # 3-D leading shape and a non-contiguous view go through the same kernels
     x3 = x0[:1536].reshape(4, 384, D)
     assert torch.equal(enc(x3), o1[:1536].reshape(4, 384, -1))
+    assert enc(x0[:0]).shape == (0, enc.out_dim)
     # raw C ABI: zero points is a no-op, bad sizes are refused
     L_ = _lib.lib()
     assert L_.pir_embed_forward(0, D, L, None, None, None) == 0

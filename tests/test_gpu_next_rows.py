@@ -114,3 +114,56 @@ def test_training_step_full_size_materials_fused_vs_eager():
     errs = {k: rel_err(g0[k], g1[k]) for k in g0}
     assert float(np.median(list(errs.values()))) < 3e-6 and max(errs.values()) < 1e-5, \
         sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
+def test_edge_walk_kernel_matches_the_stepwise_walk():
+    """pir_edge_walk (the whole surface walk in one launch) against the round-2 form of locate_edge_points (one
+    get_all launch + eager ops + a host sync per step) on the fixture's depth-edge pixels and on a 256 x 256 view:
+    same found set, same pixels, points within 1e-6 (the eager 3-vector norms may round one ulp differently); and
+    against the reference's own walk output stored in next_rows.npz."""
+    import numpy as np
+    import next_rows_util
+    from pir_amd import scene
+    from pir_amd.renderer import raytracer as rt
+    d, net, mats, dino = next_rows_util.build("cuda")
+    cam = rt.Camera(48, 48, torch.from_numpy(d["K"]).cuda(), torch.from_numpy(d["W2C"]).cuda())
+    start, mask = torch.from_numpy(d["trace.points"]).cuda(), torch.from_numpy(d["depth_edge_mask"]).cuda()
+    out = {}
+    for fused in (True, False):
+        rt.FUSED_EDGE_WALK = fused
+        try:
+            out[fused] = rt.locate_edge_points(cam, start, net, max_step=16, step_size=1e-3, dot_threshold=5e-2, mask=mask)
+        finally:
+            rt.FUSED_EDGE_WALK = True
+    a, b = out[True], out[False]
+    assert torch.equal(a["edge_mask"], b["edge_mask"]) and torch.equal(a["edge_pixel_idx"], b["edge_pixel_idx"])
+    assert (a["edge_points"] - b["edge_points"]).abs().max().item() < 1e-6
+    assert np.array_equal(a["edge_mask"].cpu().numpy(), d["edge.edge_mask"])
+    assert np.array_equal(a["edge_pixel_idx"].cpu().numpy(), d["edge.edge_pixel_idx"])
+    assert np.abs(a["edge_points"].cpu().numpy() - d["edge.edge_points"]).max() < 5e-5
+    # a larger case with several tiles, points that never reach the silhouette (max_step = 3) and an empty input
+    sdf, _, _ = scene.build_networks(seed=0, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, p in sdf.named_parameters():
+            if name.endswith("weight_v"):
+                p.add_((torch.randn(p.shape, generator=g) * 0.02 * p.std().cpu()).cuda())
+    cam2 = scene.make_camera(256, 256, device="cuda")
+    res = rt.raytrace_camera(cam2, sdf, rt.RayTracer())
+    m2 = (rt._sobel_magnitude(res["depth"]) > 1e-2) & res["convergent_mask"]
+    assert m2.sum().item() > 300
+    for max_step in (16, 3):
+        got = {}
+        for fused in (True, False):
+            rt.FUSED_EDGE_WALK = fused
+            try:
+                got[fused] = rt.locate_edge_points(cam2, res["points"], sdf, max_step=max_step, step_size=1e-3,
+                                                   dot_threshold=5e-2, mask=m2)
+            finally:
+                rt.FUSED_EDGE_WALK = True
+        assert torch.equal(got[True]["edge_pixel_idx"], got[False]["edge_pixel_idx"]), max_step
+        assert (got[True]["edge_points"] - got[False]["edge_points"]).abs().max().item() < 1e-6
+    assert got[True]["edge_points"].shape[0] < m2.sum().item()      # max_step = 3 leaves points unfinished
+    empty = rt.locate_edge_points(cam2, res["points"], sdf, max_step=16, step_size=1e-3, dot_threshold=5e-2,
+                                  mask=torch.zeros_like(m2))
+    assert empty["edge_points"].shape[0] == 0 and not empty["edge_mask"].any()

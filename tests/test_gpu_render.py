@@ -271,3 +271,9 @@ def test_two_streams_overlap_without_sharing_scratch():
                 assert torch.equal(a, b), (rep, i)
     keys = {k[:2] for k in sdf_hip._bwd_scratch_cache}
     assert len({k[1] for k in keys}) >= 3      # default stream + the two side streams each own a buffer
+    # the per-stream buffers are sized to the calls made on them: nowhere near the 8.7 GB maximum
+    side = [b.numel() for k, b in sdf_hip._bwd_scratch_cache.items() if k[1] in {int(st.cuda_stream) for st in streams}]
+    assert side and max(side) <= sdf_hip._lib.lib().pir_sdf_backward_scratch_bytes(
+        max(4096, 1 << (int(xs[0].shape[0]) - 1).bit_length()))
+    sdf_hip.free_scratch()
+    assert not sdf_hip._bwd_scratch_cache and not sdf_hip._scratch_cache
