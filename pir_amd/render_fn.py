@@ -41,9 +41,11 @@ def make_render_fn(ggx_renderer, is_metal=False, smoothness_weight=0.0):
                   "roughness_grads", "normal")
         out = {k: torch.zeros(n + [3], dtype=torch.float32, device=dev) for k in names3}
         out["specular_roughness"] = torch.zeros(n, dtype=torch.float32, device=dev)
-        any_hit = bool(interior_mask.any())
+        from .renderer.raytracer import mask_indices
+        flat_idx = mask_indices(interior_mask) if interior_mask.dim() == 1 else None   # shared with the caller's gather
+        idx = (flat_idx,) if flat_idx is not None else interior_mask.nonzero(as_tuple=True)
+        any_hit = idx[0].numel() > 0
         if any_hit:
-            idx = interior_mask.nonzero(as_tuple=True)
             from .shade_hip import UnitNormals
             if isinstance(normals, UnitNormals):   # already n / (|n| + 1e-10), from the fused shading-input kernel
                 normals = normals.as_subclass(torch.Tensor)

@@ -573,11 +573,12 @@ def render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_sa
     dots_sh = list(results["convergent_mask"].shape)
     mask = (results["convergent_mask"] | results["edge_mask"]).reshape(-1)
     vis = torch.zeros(mask.shape, dtype=torch.float32, device=mask.device)
-    if mask.any():
-        pts = results["points"].reshape(-1, 3)[mask]
+    idx = mask_indices(mask)                 # one nonzero (one host sync) for the gather and the scatter
+    if idx.numel() > 0:
+        pts = results["points"].reshape(-1, 3).index_select(0, idx)
         v = light_visibility(light_pos, pts, sdf_network, inv_s, n_samples=n_samples, is_training=is_training)
         with torch.set_grad_enabled(is_training):
-            vis = vis.index_put((mask.nonzero(as_tuple=True)[0],), v)
+            vis = vis.index_put((idx,), v)
     results.update({"vis": vis.reshape(dots_sh)})
 
 
@@ -588,10 +589,12 @@ def render_normal_and_color(results, sdf_network, color_network_dict, dino_netwo
     mask = results["convergent_mask"].reshape(-1)
     empty = torch.zeros(0, dtype=torch.float32, device=mask.device)
     fused = False
-    if mask.any():
-        points = results["points"].reshape(-1, 3)[mask]
-        ray_d = results["ray_d"].reshape(-1, 3)[mask]
-        ray_o = results["ray_o"].reshape(-1, 3)[mask]
+    idx = mask_indices(mask)                 # shared with render_fn's scatter: one nonzero / host sync per call
+    any_hit = idx.numel() > 0
+    if any_hit:
+        points = results["points"].reshape(-1, 3).index_select(0, idx)
+        ray_d = results["ray_d"].reshape(-1, 3).index_select(0, idx)
+        ray_o = results["ray_o"].reshape(-1, 3).index_select(0, idx)
         sdf, feature, normal = sdf_network.get_all(points, is_training=is_training)
         dino_feature = dino_network(points, is_training=False)
         fused = points.is_cuda and FUSED_SHADE_INPUTS and getattr(render_fn, "accepts_unit_normals", False)
@@ -609,7 +612,7 @@ def render_normal_and_color(results, sdf_network, color_network_dict, dino_netwo
         if not fused:
             lightdir = distance = None
             if light_pos is not None:
-                if mask.any():
+                if any_hit:
                     lightdir = F.normalize(points - light_pos, eps=1e-10)
                     distance = (points - light_pos).norm(dim=-1, keepdim=True)
                 else:
@@ -620,6 +623,21 @@ def render_normal_and_color(results, sdf_network, color_network_dict, dino_netwo
     for k, v in render_results.items():
         v = v.reshape(dots_sh + [-1])
         results[k] = v.squeeze(-1) if v.shape[-1] == 1 else v
+
+
+_nz_cache = [None, None, None]     # [weakref to the mask tensor, its version, indices]
+
+
+def mask_indices(mask):
+    """mask.nonzero() of a flat bool mask, remembered for the SAME tensor object at the same version: the drivers
+    below and render_fn index several arrays by one mask; a boolean index costs a nonzero + a host sync each time."""
+    import weakref
+    ref, ver, idx = _nz_cache
+    if ref is not None and ref() is mask and ver == mask._version:
+        return idx
+    idx = mask.nonzero(as_tuple=True)[0]
+    _nz_cache[:] = [weakref.ref(mask), mask._version, idx]
+    return idx
 
 
 def _put_rows(img, idx, rows):
@@ -648,13 +666,26 @@ def render_edge_pixels(results, camera, sdf_network, raytracer, color_network_di
     alpha = 2 * torch.arccos(torch.clamp(dot2d / pixel_radius, min=0.0, max=1.0))
     w_pos = (1.0 - (alpha - torch.sin(alpha)) / (2.0 * np.pi)).unsqueeze(-1)
 
-    sides = []
-    for side_uv in (centre - pixel_radius * n2d, centre + pixel_radius * n2d):   # positive side, negative side
-        r = raytrace_pixels(sdf_network, raytracer, side_uv, camera)
+    side_uvs = (centre - pixel_radius * n2d, centre + pixel_radius * n2d)        # positive side, negative side
+    E = edge_uv.shape[0]
+    if 0 < E <= 200000:
+        # Both sides in ONE trace and ONE shading call (half the launches and gradient accumulations).  Rays are
+        # independent except for the bisection loop, which the reference runs until every ray of a CALL is done
+        # (raytracer.py:234): max_num_rays = E keeps the two sides in separate chunks of the tracer, so each side
+        # bisects exactly as in a call of its own.
+        r = raytrace_pixels(sdf_network, raytracer, torch.cat(side_uvs, dim=0), camera, max_num_rays=E)
         render_normal_and_color(r, sdf_network, color_network_dict, dino_network, render_fn,
                                 is_training=is_training, light_pos=light_pos, roughness_warmup=roughness_warmup)
-        sides.append(r)
-    pos, neg = sides
+        pos = {k: (v[:E] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * E else v) for k, v in r.items()}
+        neg = {k: (v[E:] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * E else v) for k, v in r.items()}
+    else:
+        sides = []
+        for side_uv in side_uvs:
+            r = raytrace_pixels(sdf_network, raytracer, side_uv, camera)
+            render_normal_and_color(r, sdf_network, color_network_dict, dino_network, render_fn,
+                                    is_training=is_training, light_pos=light_pos, roughness_warmup=roughness_warmup)
+            sides.append(r)
+        pos, neg = sides
 
     def mix(key):
         a, b = pos[key], neg[key]
