@@ -71,12 +71,19 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
               int n_steps, long chunk, int max_bisect, unsigned char* convergent, float* points, float* sdf,
               float* distance, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Parity output: for every ray of the LAST pir_trace on this workspace (same n_rays / chunk / max_bisect), the index
+ * of the first negative sample the dense sampler found = `min_idx` of RayTracer.ray_sampler (raytracer.py:192-197)
+ * where its min_val < 0; -1 = sampled without a negative sample; -2 = the ray never reached the sampler.
+ * min_idx: DEVICE int[n_rays], written in stream order. */
+int pir_trace_sampler_index(const void* workspace, long n_rays, long chunk, int max_bisect, int* min_idx,
+                            void* stream);
+
 /* Synchronising read-back of the tracer status word (*host_status: 0 ok, 1 bisection bound hit). */
 int pir_trace_status(const void* workspace, int* host_status, void* stream);
 
 /* pir_trace for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs and results as pir_trace,
- * but the tracer workspace is a 2.1 MB array inside the library's device image (one copy per GPU, held until the
+ * but the tracer workspace is a 2.4 MB array inside the library's device image (one copy per GPU, held until the
  * process ends) and the call performs no allocation of any kind.  Limits: n_rays <= PIR_TRACE_STATIC_MAX_RAYS
  * (a 256 x 256 view: the largest training patch, render_surface.py:556-559) and at most 64 chunks, else
  * PIR_ERR_TOO_LARGE.  status: optional DEVICE int that receives the tracer status word (0 ok, 1 bisection bound
@@ -118,6 +125,13 @@ int pir_visibility_backward(const float* g_vis, const float* sdf, const float* n
                             float* g_normal, float* g_rays_d, float* g_length, void* stream);
 
 /* ---- GGX point-light shader (src/renderer/renderer_ggx.py:39-127, GGXColocatedRenderer.forward) ------ */
+
+/* Parity output: the table bins of GGXColocatedRenderer.forward (renderer_ggx.py:88-112) for every point --
+ * idx_wi / idx_wo = clamp(ty * 100 + floor(cos^0.25 * 100)) into the n_rough-entry table for the light / view
+ * cosine, idx_diff = clamp(ty) into the n_diff-entry table, ty = floor((alpha / 4)^0.25 * 50) -- computed by the same
+ * device function as pir_ggx_forward / _backward.  Integer work: must equal the reference's indices exactly. */
+int pir_ggx_table_indices(long P, const float* normal, const float* lightdir, const float* viewdir, const float* alpha,
+                          int n_rough, int n_diff, int* idx_wi, int* idx_wo, int* idx_diff, void* stream);
 
 /* light: device scalar, or [P,3] radiance when light_is_rgb; direct_radiance = EDirectRadiance. */
 int pir_ggx_forward(long P, const float* light, int light_is_rgb, int direct_radiance, const float* distance,

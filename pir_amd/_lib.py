@@ -78,6 +78,10 @@ def _declare(L):
         fn = getattr(L, name)
         fn.restype = i32
         fn.argtypes = [lg, i32, i32] + [vp] * n_ptr + [vp]
+    L.pir_trace_sampler_index.restype = i32
+    L.pir_trace_sampler_index.argtypes = [vp, lg, lg, i32, vp, vp]
+    L.pir_ggx_table_indices.restype = i32
+    L.pir_ggx_table_indices.argtypes = [lg, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.pir_edge_walk.restype = i32
     L.pir_edge_walk.argtypes = [vp, lg, vp, vp, i32, f32, f32, vp, vp, sz, vp]
     L.pir_mlp_product_floats.restype = sz

@@ -57,6 +57,30 @@ __device__ __forceinline__ float smith_g1(float c, float a) {
   return 2.0f / (1.0f + hypotf(rt, 1.0f));
 }
 
+// x ** 0.25 as torch computes it for fp32 tensors on the CPU the fixtures come from (a <= 1 ulp vectorised pow):
+// the correctly rounded value, obtained in double (two exact-rounded square roots, then one rounding to float).
+// The bare powf differs from it by an ulp on a few inputs, and an ulp decides the bin when w * 100 sits on an integer.
+__device__ __forceinline__ float pow_quarter(float x) {
+#ifdef PIR_GGX_POWF      // A/B: the round-2 form
+  return powf(x, 0.25f);
+#else
+  return (float)sqrt(sqrt((double)x));
+#endif
+}
+
+// Table bins of the rough-transmittance lookups (renderer_ggx.py:88-112): tx = floor(cos^0.25 * 100),
+// ty = floor((alpha / 4)^0.25 * 50), index = ty * 100 + tx clamped to the table; the 50-entry table uses ty clamped.
+__device__ __forceinline__ void ggx_table_indices(float a, float ci, float co, const GgxTables& tb, long& ii, long& io,
+                                                  long& id) {
+  const float wa = pow_quarter(a / 4.0f);
+  const long ty = (long)floorf(wa * 50.0f);
+  ii = ty * 100 + (long)floorf(pow_quarter(ci) * 100.0f);
+  io = ty * 100 + (long)floorf(pow_quarter(co) * 100.0f);
+  ii = ii < 0 ? 0 : (ii > tb.n_rough - 1 ? tb.n_rough - 1 : ii);
+  io = io < 0 ? 0 : (io > tb.n_rough - 1 ? tb.n_rough - 1 : io);
+  id = ty < 0 ? 0 : (ty > tb.n_diff - 1 ? tb.n_diff - 1 : ty);
+}
+
 __device__ __forceinline__ void ggx_eval(GgxPoint& p, const float* light, int light_rgb, int edr, float dist,
                                          const float (&n)[3], const float (&l)[3], const float (&v)[3], float alpha,
                                          const GgxTables& tb) {
@@ -88,13 +112,8 @@ __device__ __forceinline__ void ggx_eval(GgxPoint& p, const float* light, int li
   p.inv4ci = 1.0f / (4.0f * p.ci + 1e-10f);
   p.Ks = kF0 * p.D * (p.G1i * p.G1o) * p.inv4ci;
   // tabulated rough transmittance (floor-indexed, no gradient)
-  const float wa = powf(p.a / 4.0f, 0.25f);
-  const long ty = (long)floorf(wa * 50.0f);
-  long ii = ty * 100 + (long)floorf(powf(p.ci, 0.25f) * 100.0f);
-  long io = ty * 100 + (long)floorf(powf(p.co, 0.25f) * 100.0f);
-  ii = ii < 0 ? 0 : (ii > tb.n_rough - 1 ? tb.n_rough - 1 : ii);
-  io = io < 0 ? 0 : (io > tb.n_rough - 1 ? tb.n_rough - 1 : io);
-  const long id = ty < 0 ? 0 : (ty > tb.n_diff - 1 ? tb.n_diff - 1 : ty);
+  long ii, io, id;
+  ggx_table_indices(p.a, p.ci, p.co, tb, ii, io, id);
   const float T12 = fminf(fmaxf(tb.rough[ii], 0.0f), 1.0f);
   const float T21 = fminf(fmaxf(tb.rough[io], 0.0f), 1.0f);
   const float Fdr = fminf(fmaxf(1.0f - tb.diff[id], 0.0f), 1.0f);
@@ -278,7 +297,34 @@ static unsigned ggx_grid(long P) {
 
 using namespace pir;
 
+// Debug / parity output: the table bins every point lands in (same device function as the shading kernels).
+__global__ void ggx_indices_kernel(long P, const float* __restrict__ normal, const float* __restrict__ ldir,
+                                   const float* __restrict__ vdir, const float* __restrict__ alpha, GgxTables tb,
+                                   int* __restrict__ idx_i, int* __restrict__ idx_o, int* __restrict__ idx_d) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P) return;
+  const float n[3] = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+  const float co_raw = vdir[3 * i] * n[0] + vdir[3 * i + 1] * n[1] + vdir[3 * i + 2] * n[2];
+  const float ci_raw = ldir[3 * i] * n[0] + ldir[3 * i + 1] * n[1] + ldir[3 * i + 2] * n[2];
+  const float co = fminf(fmaxf(co_raw, kLo), kHi), ci = fminf(fmaxf(ci_raw, kLo), kHi);
+  const float a = fmaxf(alpha[i], 0.0001f);
+  long ii, io, id;
+  ggx_table_indices(a, ci, co, tb, ii, io, id);
+  idx_i[i] = (int)ii; idx_o[i] = (int)io; idx_d[i] = (int)id;
+}
+
 extern "C" {
+
+int pir_ggx_table_indices(long P, const float* normal, const float* lightdir, const float* viewdir, const float* alpha,
+                          int n_rough, int n_diff, int* idx_wi, int* idx_wo, int* idx_diff, void* stream) {
+  if (P < 0 || n_rough <= 0 || n_diff <= 0) return PIR_ERR_ARG;
+  if (P == 0) return PIR_OK;
+  if (!normal || !lightdir || !viewdir || !alpha || !idx_wi || !idx_wo || !idx_diff) return PIR_ERR_ARG;
+  GgxTables tb{nullptr, n_rough, nullptr, n_diff};
+  hipLaunchKernelGGL(ggx_indices_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, normal,
+                     lightdir, viewdir, alpha, tb, idx_wi, idx_wo, idx_diff);
+  return pir_check_launch();
+}
 
 int pir_ggx_forward(long P, const float* light, int light_is_rgb, int direct_radiance, const float* distance,
                     const float* normal, const float* lightdir, const float* viewdir, const float* kd, const float* ks,

@@ -16,6 +16,8 @@ struct TraceWs {
   int* blist;       // rays handed to bisection
   float* d_lo; float* d_hi; float* f_lo; float* f_hi;   // bisection brackets, indexed by ray
   unsigned char* bwork;                                    // per-ray bisection work flag
+  int* min_idx;     // per ray: index of the first negative sample of the dense sampler (raytracer.py:192-197);
+                    // -1 = sampled, no negative sample; -2 = the ray never reached the sampler
   int* counters;    // [0..17] list sizes per sphere-trace eval (17 = sampler list), [32] bisect count, [33] status,
                     // [34] rays left after the sampler's head pass (listed in list[0])
   int* flags;       // [(max_bisect + 1)][nchunks] "any ray still bisecting" per reference chunk
@@ -60,6 +62,7 @@ __global__ void trace_init_kernel(long N, const float* __restrict__ ray_o, const
   for (int c = 0; c < 3; ++c) pts[3 * i + c] = add_rn(ray_o[3 * i + c], mul_rn(ray_d[3 * i + c], a));
   conv[i] = 0;
   ws.list[0][i] = (int)i;
+  ws.min_idx[i] = -2;
 }
 
 // One sphere-tracing evaluation (reference loop body, raytracer.py:142-156): eval `it` of 0..max_iters.
@@ -191,6 +194,7 @@ sampler_kernel(SdfPacked pk, const int* __restrict__ rays, int count_idx, int fi
       __syncthreads();
       if (s_found >= 0) break;
     }
+    if (threadIdx.x == 0) ws.min_idx[r] = s_found;
     if (threadIdx.x == 0 && s_found < 1) {
       // no sign change (or a negative first sample): the reference returns zeros and "not convergent"
       pts[3 * r] = 0.f; pts[3 * r + 1] = 0.f; pts[3 * r + 2] = 0.f;
@@ -245,6 +249,7 @@ sampler_head_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nch
       int r = 0;
       if (valid && i == 0) {
         r = ws.slist[q];
+        if (first >= 0) ws.min_idx[r] = first;
         if (first < 0) {                              // no negative sample yet: continue from sample kHead
           cont = true;
           ws.f_lo[r] = v_last;
@@ -369,7 +374,9 @@ static size_t ws_layout(long N, int nchunks, int max_bisect, char* base, TraceWs
   char* a = take(sizeof(float) * N); char* b = take(sizeof(float) * N);
   char* c = take(sizeof(float) * N); char* d = take(sizeof(float) * N);
   char* bw = take(N);
+  char* mi = take(sizeof(int) * N);
   if (ws) {
+    ws->min_idx = (int*)mi;
     ws->counters = (int*)cnt; ws->flags = (int*)cnt + kNumCounters;
     ws->list[0] = (int*)l0; ws->list[1] = (int*)l1; ws->slist = (int*)sl; ws->blist = (int*)bl;
     ws->d_lo = (float*)a; ws->d_hi = (float*)b; ws->f_lo = (float*)c; ws->f_hi = (float*)d; ws->bwork = (unsigned char*)bw;
@@ -481,16 +488,24 @@ int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* 
 constexpr long kStaticMaxRays = PIR_TRACE_STATIC_MAX_RAYS;
 constexpr int kStaticMaxChunks = 64;
 constexpr size_t kStaticHeader = (sizeof(int) * (kNumCounters + (64 + 2) * kStaticMaxChunks) + 255) & ~(size_t)255;
-constexpr size_t kStaticBytes = kStaticHeader + 8 * sizeof(int) * kStaticMaxRays + kStaticMaxRays;   // 2 179 840
+constexpr size_t kStaticBytes = kStaticHeader + 9 * sizeof(int) * kStaticMaxRays + kStaticMaxRays;   // 2 441 984
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 static std::mutex g_static_mu;
 static char* g_static_ptr[64] = {nullptr};   // per device: address of that device's copy of `scratch`
 
 // Device address of the current device's `scratch`, looked up once per device.
-static char* static_workspace() {
+// The kernels run on the device that owns `stream`; that must be the current device (NULL stream: it is by definition),
+// otherwise the array of another GPU would be handed to them.
+static char* static_workspace(hipStream_t stream, int* err) {
   int dev = -1;
+  *err = PIR_ERR_LAUNCH;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (stream) {
+    hipDevice_t sdev = -1;
+    if (hipStreamGetDevice(stream, &sdev) != hipSuccess) return nullptr;
+    if ((int)sdev != dev) { *err = PIR_ERR_ARG; return nullptr; }
+  }
   std::lock_guard<std::mutex> lk(g_static_mu);
   if (!g_static_ptr[dev]) {
     void* p = nullptr;
@@ -516,8 +531,9 @@ int pir_trace_static(const void* packed, long n_rays, const float* ray_o, const 
   const int nchunks = (int)((n_rays + chunk - 1) / chunk);
   if (nchunks > kStaticMaxChunks) return PIR_ERR_TOO_LARGE;
   if (ws_layout(n_rays, nchunks, max_bisect, nullptr, nullptr) > kStaticBytes) return PIR_ERR_TOO_LARGE;
-  char* ws = static_workspace();
-  if (!ws) return PIR_ERR_LAUNCH;
+  int ws_err = PIR_OK;
+  char* ws = static_workspace((hipStream_t)stream_, &ws_err);
+  if (!ws) return ws_err;
   const int rc2 = trace_enqueue(packed, n_rays, ray_o, ray_d, min_dis, max_dis, work_mask, sdf_threshold,
                                 sphere_tracing_iters, n_steps, chunk, nchunks, max_bisect, convergent, points, sdf,
                                 distance, ws, stream_);
@@ -526,6 +542,18 @@ int pir_trace_static(const void* packed, long n_rays, const float* ray_o, const 
                                (hipStream_t)stream_) != hipSuccess)
     return PIR_ERR_LAUNCH;
   return PIR_OK;
+}
+
+int pir_trace_sampler_index(const void* workspace, long n_rays, long chunk, int max_bisect, int* min_idx,
+                            void* stream_) {
+  if (n_rays < 0 || max_bisect < 1 || max_bisect > 64) return PIR_ERR_ARG;
+  if (n_rays == 0) return PIR_OK;
+  if (!workspace || !min_idx) return PIR_ERR_ARG;
+  if (chunk <= 0) chunk = n_rays;
+  TraceWs ws;
+  ws_layout(n_rays, (int)((n_rays + chunk - 1) / chunk), max_bisect, (char*)workspace, &ws);
+  return hipMemcpyAsync(min_idx, ws.min_idx, sizeof(int) * (size_t)n_rays, hipMemcpyDeviceToDevice,
+                        (hipStream_t)stream_) == hipSuccess ? PIR_OK : PIR_ERR_LAUNCH;
 }
 
 int pir_trace_status(const void* workspace, int* host_status, void* stream_) {

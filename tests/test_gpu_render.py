@@ -277,3 +277,57 @@ def test_two_streams_overlap_without_sharing_scratch():
         max(4096, 1 << (int(xs[0].shape[0]) - 1).bit_length()))
     sdf_hip.free_scratch()
     assert not sdf_hip._bwd_scratch_cache and not sdf_hip._scratch_cache
+
+
+def test_ggx_table_bins_equal_the_reference_bit_for_bit():
+    """Integer work must be bit-exact: the table bins pir_ggx_forward / _backward use (floor(cos^0.25 * 100),
+    floor((alpha/4)^0.25 * 50), clamped) against the reference's own torch.floor outputs on the 4096 points of ggx.npz
+    (indices.npz; clamp-edge cosines, alpha below / above the table range included), both light configurations."""
+    from pir_amd import _lib
+    d, ix = load_golden("ggx.npz"), load_golden("indices.npz")
+    P = d["normal"].shape[0]
+    cu = lambda k: torch.from_numpy(d[k]).cuda().contiguous()  # noqa: E731
+    total = 0
+    for tag, ldir in (("offset", "lightdir"), ("coloc", "viewdir")):
+        out = [torch.empty(P, dtype=torch.int32, device="cuda") for _ in range(3)]
+        rc = _lib.lib().pir_ggx_table_indices(P, _lib.ptr(cu("normal")), _lib.ptr(cu(ldir)), _lib.ptr(cu("viewdir")),
+                                              _lib.ptr(cu("alpha")), 5000, 50, *[_lib.ptr(t) for t in out],
+                                              _lib.stream_ptr())
+        assert rc == 0
+        for t, key in zip(out, ("idx_wi", "idx_wo", "idx_diff")):
+            ref = ix[f"ggx.{tag}.{key}"]
+            bad = np.nonzero(t.cpu().numpy() != ref)[0]
+            total += bad.size
+            assert bad.size == 0, (tag, key, bad.size, bad[:8], t.cpu().numpy()[bad[:8]], ref[bad[:8]])
+    print("GGX table bins: 0 of", 6 * P, "differ from the reference's")
+
+
+@pytest.mark.parametrize("name", ["trace_crop800", "trace_bumpy64", "trace_std64"])
+def test_sampler_first_negative_index_equals_the_reference_min_idx(name):
+    """The dense sampler's index work (raytracer.py:192-197): for every ray the reference hands to ray_sampler, the
+    first negative sample found by the HIP sampler equals the reference's min_idx (where its min_val < 0), rays
+    without a negative sample report none, and exactly the reference's rays reach the sampler."""
+    from pir_amd import _lib
+    from pir_amd.renderer import raytracer as rt
+    d, ix = load_golden(name + ".npz"), load_golden("indices.npz")
+    net = sdf_net("sdf_full.npz" if name == "trace_std64" else "sdf_full_bumpy_weights.npz")
+    cam = rt.Camera(int(d["W"]), int(d["H"]), torch.from_numpy(d["K"]).cuda(), torch.from_numpy(d["W2C"]).cuda())
+    ray_o, ray_d, _ = cam.get_rays(cam.get_uv())
+    ray_o, ray_d = ray_o.reshape(-1, 3).contiguous(), ray_d.reshape(-1, 3).contiguous()
+    n = ray_o.shape[0]
+    tracer = rt.RayTracer()
+    res = tracer(rt.SdfCallable(net), ray_o, ray_d, torch.from_numpy(d["min_dis"]).cuda(),
+                 torch.from_numpy(d["max_dis"]).cuda(), torch.from_numpy(d["work_mask"]).cuda())
+    assert np.array_equal(res["convergent_mask"].cpu().numpy(), d["convergent_mask"])
+    ws = rt._trace_ws[_lib.stream_key(ray_o.device)]
+    idx = torch.empty(n, dtype=torch.int32, device="cuda")
+    assert _lib.lib().pir_trace_sampler_index(_lib.ptr(ws), n, 0, tracer.max_bisect, _lib.ptr(idx), _lib.stream_ptr()) == 0
+    idx = idx.cpu().numpy()
+    rays, ref_idx, neg = ix[name + ".sampler_rays"], ix[name + ".min_idx"], ix[name + ".min_val_negative"]
+    in_sampler = np.zeros(n, bool)
+    in_sampler[rays] = True
+    assert np.array_equal(idx != -2, in_sampler), ((idx != -2) != in_sampler).sum()
+    got = idx[rays]
+    assert np.array_equal(got[neg], ref_idx[neg]), (got[neg] != ref_idx[neg]).sum()
+    assert (got[~neg] == -1).all()
+    print(f"{name}: {rays.size} rays in the sampler, first-negative index equal on all {int(neg.sum())} with one")

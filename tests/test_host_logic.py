@@ -392,3 +392,11 @@ def test_embedder_class_matches_get_embedder():
                    periodic_fns=[torch.sin])
     assert lin.out_dim == 8 and lin.freq_bands[0] == 1.0 and lin.freq_bands[-1] == 8.0
     assert lin.embed(torch.rand(4, 2)).shape == (4, 8)
+
+
+def test_training_trajectory_five_steps_matches_reference_cpu():
+    """Five consecutive iterations of the reference loop across a phase change of its optimizer schedule
+    (train_traj.npz): per-step losses, view / crop choice, masks, which networks move, parameters after step 5."""
+    import train_traj_util
+    out = train_traj_util.run("cpu", loss_tol=2e-4)
+    assert out["comparable"] and len(out["losses"]) == 5

@@ -646,6 +646,61 @@ def main():
         print("train trajectory: losses", per_step["loss"], "hits", hits, "edges", edges, "shadow", shadow, "idx", idxs)
         save(os.path.join(out_dir, "train_traj.npz"), **tj)
 
+    # ------------------------------------------------ integer work (round 3): the reference's own
+    # table bins of the GGX shader (renderer_ggx.py:94-99, :115: the outputs of its five torch.floor calls) on the
+    # inputs of ggx.npz, and the dense sampler's min_idx (raytracer.py:192-197: the output of its torch.min) on the
+    # rays of the tracer fixtures.  Captured by recording what torch.floor / torch.min return while the reference
+    # code runs, so that nothing is restated here.
+    if not only or "indices.npz" in only:
+        gz = np.load(os.path.join(out_dir, "ggx.npz"))
+        T = lambda k: torch.from_numpy(gz[k])  # noqa: E731
+        ix = {}
+        real_floor, real_min = torch.floor, torch.min
+        for tag, ldir_key in (("offset", "lightdir"), ("coloc", "viewdir")):
+            rec = []
+            torch.floor = lambda x, _r=rec: (_r.append(real_floor(x)), _r[-1])[1]
+            try:
+                with torch.no_grad():
+                    ggx(torch.tensor(135.0), T("distance"), T("normal"), T(ldir_key), T("viewdir"), T("kd"), T("ks"),
+                        T("alpha"))
+            finally:
+                torch.floor = real_floor
+            assert len(rec) == 5, len(rec)
+            tx_wi, ty_wi, tx_wo, ty_wo, t_idx = [r.long().reshape(-1).numpy() for r in rec]
+            ix[f"ggx.{tag}.idx_wi"] = np.clip(ty_wi * 100 + tx_wi, 0, 4999).astype(np.int32)
+            ix[f"ggx.{tag}.idx_wo"] = np.clip(ty_wo * 100 + tx_wo, 0, 4999).astype(np.int32)
+            ix[f"ggx.{tag}.idx_diff"] = np.clip(t_idx, 0, 49).astype(np.int32)
+        for name, net in (("trace_crop800.npz", net_bumpy), ("trace_bumpy64.npz", net_bumpy), ("trace_std64.npz", net_full)):
+            tz = np.load(os.path.join(out_dir, name))
+            W_, H_ = int(tz["W"]), int(tz["H"])
+            cam = rt.Camera(W_, H_, torch.from_numpy(tz["K"]), torch.from_numpy(tz["W2C"]))
+            ray_o, ray_d, _ = cam.get_rays(cam.get_uv())
+            ray_o, ray_d = ray_o.reshape(-1, 3), ray_d.reshape(-1, 3)
+            rec = []
+
+            def rec_min(*a, _r=rec, **k):
+                out = real_min(*a, **k)
+                if k.get("dim", None) == -1:
+                    _r.append(out)
+                return out
+            torch.min = rec_min
+            try:
+                with torch.no_grad():
+                    full = tracer(lambda x, _n=net: _n(x)[..., 0], ray_o, ray_d, torch.from_numpy(tz["min_dis"]),
+                                  torch.from_numpy(tz["max_dis"]), torch.from_numpy(tz["work_mask"]))
+            finally:
+                torch.min = real_min
+            assert np.array_equal(_np(full["convergent_mask"]), tz["convergent_mask"])
+            assert len(rec) == 1, len(rec)
+            stem = name[:-4]
+            ix[f"{stem}.sampler_rays"] = np.nonzero(tz["st_unfinished"].reshape(-1))[0].astype(np.int32)
+            ix[f"{stem}.min_idx"] = rec[0][1].numpy().astype(np.int32)
+            ix[f"{stem}.min_val_negative"] = (rec[0][0] < 0).numpy()
+            assert ix[f"{stem}.min_idx"].shape == ix[f"{stem}.sampler_rays"].shape
+            print(f"indices: {stem}: {len(ix[stem + '.min_idx'])} rays in the sampler, "
+                  f"{int(ix[stem + '.min_val_negative'].sum())} with a negative sample")
+        save(os.path.join(out_dir, "indices.npz"), **ix)
+
     # known-answer GGX cases of SURVEY.md Appendix A are asserted directly in the tests.
     tot = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
     print("wrote fixtures to", out_dir, "total bytes", tot)
