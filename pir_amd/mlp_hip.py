@@ -417,7 +417,9 @@ class _MlpBwdFn(torch.autograd.Function):
 
 def mlp_apply_fused(mod, inp):
     lins = module_layers(mod)
-    wb = [l.effective_weight() for l in lins] + [l.bias for l in lins]
+    # shared_weight(): ONE weight-norm node per layer and optimisation step, shared by every evaluation of the network
+    # (direct shading, both indirect shades, the edge sides): no weight-norm launches per call, one backward per step
+    wb = [l.shared_weight() for l in lins] + [l.bias for l in lins]
     return _MlpFn.apply(mod, inp, *wb)
 
 

@@ -18,6 +18,66 @@ from .models.embedder import get_embedder
 from . import sdf_autograd
 
 
+class _WeightNormFn(torch.autograd.Function):
+    """W = g v / |v| (rows) as ONE graph node that can be shared by every evaluation of a network within an
+    optimisation step and traversed by any number of backward calls: it keeps v, g and the row norms as plain
+    attributes instead of autograd-saved tensors (which a first backward would free).  Same kernels as
+    torch._weight_norm (aten::_weight_norm_interface and its backward)."""
+
+    @staticmethod
+    def forward(ctx, v, g):
+        w, norms = torch._weight_norm_interface(v, g, 0)
+        ctx.v, ctx.g, ctx.norms = v, g, norms
+        ctx.versions = (v._version, g._version)
+        return w
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gw):
+        if (ctx.v._version, ctx.g._version) != ctx.versions:
+            raise RuntimeError("pir_amd: a weight-normed parameter was modified in place between the forward pass and "
+                               "the backward pass that differentiates it")
+        gv, gg = torch.ops.aten._weight_norm_interface_backward(gw.contiguous(), ctx.v, ctx.g, ctx.norms, 0)
+        return gv, gg
+
+
+class _SdfThetaFn(torch.autograd.Function):
+    """All effective weights and biases of an SDFNetwork as ONE flat tensor theta = [W_0 .. W_8 | b_0 .. b_8]: every
+    kernel call of a step takes theta as its single parameter input and returns a single flat gradient, so autograd
+    adds one tensor per call instead of 27 and runs the weight-norm backward once per step instead of once per call.
+    Like _WeightNormFn it holds its inputs as attributes, so several backward calls may traverse it."""
+
+    @staticmethod
+    def forward(ctx, *vgb):
+        n = len(vgb) // 3
+        vs, gs, bs = vgb[:n], vgb[n:2 * n], vgb[2 * n:]
+        ws, norms = [], []
+        for v, g in zip(vs, gs):
+            w, nr = torch._weight_norm_interface(v, g, 0)
+            ws.append(w.reshape(-1))
+            norms.append(nr)
+        ctx.vs, ctx.gs, ctx.norms = vs, gs, norms
+        ctx.versions = tuple(t._version for t in vs + gs)
+        ctx.sizes = [w.numel() for w in ws] + [b.numel() for b in bs]
+        return torch.cat(ws + [b.reshape(-1) for b in bs])
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_theta):
+        if tuple(t._version for t in ctx.vs + ctx.gs) != ctx.versions:
+            raise RuntimeError("pir_amd: an SDF parameter was modified in place between the forward pass and the "
+                               "backward pass that differentiates it")
+        n = len(ctx.vs)
+        parts = torch.split(g_theta, ctx.sizes)
+        gvs, ggs = [], []
+        for l in range(n):
+            gv, gg = torch.ops.aten._weight_norm_interface_backward(parts[l].view(ctx.vs[l].shape), ctx.vs[l], ctx.gs[l],
+                                                                    ctx.norms[l], 0)
+            gvs.append(gv)
+            ggs.append(gg)
+        return (*gvs, *ggs, *[parts[n + l].view(-1) for l in range(n)])
+
+
 class WNLinear(nn.Module):
     """Linear layer with old-style weight normalisation along dim 0 (parameters weight_g [out,1],
     weight_v [out,in], bias [out]) -- the parameter set nn.utils.weight_norm(nn.Linear) exposes."""
@@ -47,6 +107,18 @@ class WNLinear(nn.Module):
         if not self.weight_norm:
             return self.weight
         return torch._weight_norm(self.weight_v, self.weight_g, 0)
+
+    def shared_weight(self):
+        """effective_weight() as a graph node shared by all calls until a parameter changes (GPU kernel paths: one
+        weight-norm launch per optimisation step instead of one per network evaluation, and one weight-norm backward)."""
+        if not self.weight_norm:
+            return self.weight
+        key = (self.weight_v.data_ptr(), self.weight_v._version, self.weight_g.data_ptr(), self.weight_g._version,
+               self.weight_v.requires_grad, self.weight_g.requires_grad, torch.is_grad_enabled())
+        if getattr(self, "_shared_key", None) != key:
+            self._shared_w = _WeightNormFn.apply(self.weight_v, self.weight_g)
+            self._shared_key = key
+        return self._shared_w
 
     def forward(self, x):
         return F.linear(x, self.effective_weight(), self.bias)
@@ -127,6 +199,17 @@ class SDFNetwork(nn.Module):
 
     def effective_weights(self):
         return [lin.effective_weight() for lin in self.layers()], [lin.bias for lin in self.layers()]
+
+    def theta(self):
+        """[W_0 .. W_8 | b_0 .. b_8] flat, with its graph to the parameters, shared by all kernel calls until a parameter
+        changes (_SdfThetaFn)."""
+        lins = self.layers()
+        ps = [l.weight_v for l in lins] + [l.weight_g for l in lins] + [l.bias for l in lins]
+        key = tuple((p.data_ptr(), p._version, p.requires_grad) for p in ps) + (torch.is_grad_enabled(),)
+        if getattr(self, "_theta_key", None) != key:
+            self._theta = _SdfThetaFn.apply(*ps)
+            self._theta_key = key
+        return self._theta
 
     def hip_supported(self):
         from .sdf_hip import supported_architecture

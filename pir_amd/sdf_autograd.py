@@ -17,7 +17,7 @@ stats = {}
 
 class _SdfGetAll(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, net, want_feature, want_normal, x, *wb):
+    def forward(ctx, net, want_feature, want_normal, x, theta):
         packed = net.packed()
         if want_normal:
             sdf, feat, nrm = packed.get_all(x, want_feature=want_feature)
@@ -66,19 +66,21 @@ class _SdfGetAll(torch.autograd.Function):
                 gx = torch.zeros_like(x).index_copy_(0, sel, gx_sel)
         else:
             gws, gbs, gx = sdf_hip.get_all_backward(ctx.packed, x, g_sdf, g_feat, g_nrm, ctx.need_gx)
-        return (None, None, None, gx, *gws, *gbs)
+        # gws / gbs are consecutive views of one flat allocation laid out like theta: hand it back as one gradient
+        return (None, None, None, gx, sdf_hip.flat_of(gws, gbs))
 
 
-def _wb(net):
-    ws, bs = net.effective_weights()
-    return list(ws) + list(bs)
+def _theta(net):
+    """The network's parameters as the kernels' single autograd input.  Weight-normed layers only (the reference's
+    configuration, src/network.py:75); theta() caches the node until a parameter changes."""
+    return net.theta()
 
 
 def sdf_get_all(net, x, want_feature=True):
-    sdf, feat, nrm = _SdfGetAll.apply(net, want_feature, True, x, *_wb(net))
+    sdf, feat, nrm = _SdfGetAll.apply(net, want_feature, True, x, _theta(net))
     return sdf, (feat if want_feature else None), nrm
 
 
 def sdf_forward(net, x):
-    sdf, feat, _ = _SdfGetAll.apply(net, True, False, x, *_wb(net))
+    sdf, feat, _ = _SdfGetAll.apply(net, True, False, x, _theta(net))
     return sdf, feat

@@ -7,6 +7,7 @@ import torch
 from . import _lib
 
 _SDF_SHAPES = [(256, 39), (256, 256), (256, 256), (217, 256), (256, 256), (256, 256), (256, 256), (256, 256), (257, 256)]
+_THETA_FLOATS = sum(a * b + a for a, b in _SDF_SHAPES)
 _scratch_cache = {}
 
 
@@ -110,6 +111,7 @@ def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: b
     gws = [parts[i].view(_SDF_SHAPES[i]) for i in range(9)]
     gbs = list(parts[9:18])
     gx = parts[18].view(M, 3) if need_gx else None
+    gws[0]._pir_flat = flat[:_THETA_FLOATS]     # [dW_0 .. dW_8 | db_0 .. db_8], the layout of SDFNetwork.theta()
 
     def prep(g, shape):
         if g is None:
@@ -125,6 +127,11 @@ def get_all_backward(packed: "PackedSdf", x, g_sdf, g_feat, g_normal, need_gx: b
             _lib.ptr(packed.buf), _lib.ptr(x), M, _lib.ptr(g_sdf), _lib.ptr(g_feat), _lib.ptr(g_normal), _lib.ptr(gx),
             wp, bp, _lib.ptr(scratch), scratch.numel(), _lib.stream_ptr()), "pir_sdf_get_all_backward")
     return gws, gbs, gx
+
+
+def flat_of(gws, gbs):
+    """The flat [dW | db] tensor behind the gradient views get_all_backward returned."""
+    return gws[0]._pir_flat
 
 
 def edge_walk(packed: "PackedSdf", points: torch.Tensor, cam_o: torch.Tensor, max_step: int, step_size: float,

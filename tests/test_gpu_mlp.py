@@ -254,7 +254,7 @@ def test_mlp_entry_points_reject_bad_arguments():
                             None, wp, wp, _lib.ptr(small), small.numel(), st)
     assert rc == 3                                                      # scratch too small
     # a plan without transposed products (packed for inference only) is refused by the backward
-    big = mlp_hip._backward_scratch(torch.device("cuda", 0), pk.n_hidden)
+    big = mlp_hip._backward_scratch(torch.device("cuda", 0), pk.n_hidden, 64)
     bad = mlp_hip.PirMlpPlan.from_buffer_copy(pk.plan)
     bad.has_bwd = 0
     rc = L.pir_mlp_backward(_lib.ptr(pk.buf), pk.mats_floats, ctypes.byref(bad), pk.k0, _lib.ptr(x), 64, _lib.ptr(out),

@@ -195,6 +195,9 @@ def test_training_trajectory_five_steps_matches_reference():
     the optimizer schedule across its phase change (all networks -> SDF + light only), weight re-packing after every
     step, the tracer status word accumulated over the steps."""
     import train_traj_util
-    out = train_traj_util.run("cuda", loss_tol=1e-3, exact_masks=False)
+    # parameters after 5 Adam steps, in units of the learning rate: Adam moves an element by ~lr * sign(g) while its
+    # gradient history is short, so elements whose gradient is at the level of fp32 round-off (most of lin0's 2^5
+    # frequency columns) legitimately step the other way; the bulk must agree
+    out = train_traj_util.run("cuda", loss_tol=1e-3, exact_masks=False, step_tol=(0.06, 0.6))
     print("trajectory:", out)
     assert len(out["losses"]) >= 2      # at least up to the first pixel that stops on the other side of the threshold

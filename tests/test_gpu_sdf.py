@@ -80,3 +80,56 @@ def test_packed_cache_follows_parameter_writes():
     invalidate_packed(net)
     c = net.sdf(x)
     assert (c - a).abs().max().item() < 1e-6
+
+
+def test_shared_parameter_node_survives_interleaved_backward_calls():
+    """All kernel calls of a step share ONE autograd node for the network parameters (SDFNetwork.theta, WNLinear.
+    shared_weight).  Unlike torch's weight-norm nodes it holds no autograd-saved tensors, so the pattern
+    forward A, forward B, backward A, backward B -- legal with the reference's per-call weight_norm -- keeps working;
+    the summed gradients equal one backward of the summed loss; an optimizer step makes the next call rebuild it."""
+    from pir_amd import scene
+    g = torch.Generator().manual_seed(3)
+    xa, xb = [((torch.rand(700, 3, generator=g) * 2 - 1) * 0.8).cuda() for _ in range(2)]
+    ca, cb = [torch.randn(700, 3, generator=g).cuda() for _ in range(2)]
+
+    def loss_of(net, x, c):
+        s, f, n = net.get_all(x.clone(), is_training=True)
+        return (s.sum() + (n * c).sum() + 0.01 * f.sum())
+    net = sdf_net("sdf_full_bumpy_weights.npz")
+    la, lb = loss_of(net, xa, ca), loss_of(net, xb, cb)
+    assert net._theta is not None
+    la.backward()
+    lb.backward()                       # the shared node is traversed a second time
+    g_two = {k: p.grad.clone() for k, p in net.named_parameters()}
+    ref = sdf_net("sdf_full_bumpy_weights.npz")
+    (loss_of(ref, xa, ca) + loss_of(ref, xb, cb)).backward()
+    for k, p in ref.named_parameters():
+        err = ((g_two[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)).item()
+        assert err < 2e-6, (k, err)
+    # a parameter update invalidates the shared node and the packed weights
+    theta_before = net._theta
+    s0 = net.get_all(xa.clone(), is_training=True)[0].detach().clone()
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2)
+    opt.step()
+    s1 = net.get_all(xa.clone(), is_training=True)[0].detach()
+    assert net._theta is not theta_before and (s1 - s0).abs().max().item() > 0
+    # modifying a parameter in place between forward and backward is refused, as autograd refuses it for saved tensors
+    l2 = loss_of(net, xa, ca)
+    with torch.no_grad():
+        net.lin3.weight_v.mul_(1.0)
+    with pytest.raises(RuntimeError):
+        l2.backward()
+    # material networks: same pattern through WNLinear.shared_weight
+    _, mats, _ = scene.build_networks(seed=0, device="cuda")
+    m = mats["specular_roughness_network"]
+    pts, nrm = xa[:256], torch.nn.functional.normalize(ca[:256], dim=-1)
+    geo, dino = torch.randn(256, 256, generator=g).cuda(), torch.randn(256, 384, generator=g).cuda()
+    o1 = m(pts, nrm, None, geo, dino).sum()
+    o2 = (m(pts * 0.5, nrm, None, geo, dino) ** 2).sum()
+    o1.backward()
+    o2.backward()
+    got = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    (m(pts, nrm, None, geo, dino).sum() + (m(pts * 0.5, nrm, None, geo, dino) ** 2).sum()).backward()
+    for k, p in m.named_parameters():
+        assert ((got[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)).item() < 2e-6, k

@@ -37,7 +37,7 @@ def _param(state, key):
     return dict(mod.named_parameters())[name]
 
 
-def run(device, loss_tol, flip_budget=3, exact_masks=True):
+def run(device, loss_tol, flip_budget=3, exact_masks=True, step_tol=(0.02, 0.25)):
     from pir_amd import train
     d, state = build_state(device)
     K = int(d["n_steps"])
@@ -81,7 +81,7 @@ def run(device, loss_tol, flip_budget=3, exact_masks=True):
             ref = d[f"after{K - 1}." + key].astype(np.float64) - d["before." + key]
             err = np.abs(got - ref) / lr
             worst[key] = (float(np.median(err)), float(np.quantile(err, 0.99)), float(err.max()))
-            assert np.median(err) < 0.02 and np.quantile(err, 0.95) < 0.25, (key, worst[key])
+            assert np.median(err) < step_tol[0] and np.quantile(err, 0.95) < step_tol[1], (key, worst[key])
         for key, ref, lr in (("light", d[f"after{K - 1}.light"], 2e-5), ("offset", d[f"after{K - 1}.offset"], 1e-4)):
             got = npy(pl.light if key == "light" else pl.light_offset.weight)
             assert np.abs(got - ref).max() < 0.05 * lr * K + 1e-6 * abs(float(np.abs(ref).max())), (key, got, ref)
