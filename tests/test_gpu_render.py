@@ -332,7 +332,25 @@ def test_sampler_first_negative_index_equals_the_reference_min_idx(name):
     assert other_side <= max(2, rays.size // 500), other_side
     common = idx[rays] != -2
     got = idx[rays]
-    assert np.array_equal(got[neg & common], ref_idx[neg & common]), (got[neg & common] != ref_idx[neg & common]).sum()
-    assert (got[~neg & common] == -1).all()
+    ref_first = np.where(neg, ref_idx, -1)                  # the reference's first negative sample, -1 = none
+    differ = np.nonzero(common & (got != ref_first))[0]
+    # Where the index differs the SIGN of a sample differs, i.e. the SDF at that sample is zero to within fp32
+    # round-off (grazing rays of the 16x zoomed silhouette crop run along the surface): checked sample by sample.
+    # The earlier of the two indices is the disputed sample (one side saw it negative, the other did not).
+    if differ.size:
+        r = rays[differ]
+        st_sdf, st_dis = d["st_sdf"].reshape(-1)[r], d["st_dis"].reshape(-1)[r]
+        lo = np.where(st_sdf > 0, st_dis, d["min_dis"].reshape(-1)[r]).astype(np.float32)
+        hi = np.where(st_sdf > 0, d["max_dis"].reshape(-1)[r], st_dis).astype(np.float32)
+        a, b = got[differ].astype(np.int64), ref_first[differ].astype(np.int64)
+        k = np.where((a >= 0) & ((b < 0) | (a < b)), a, b)
+        t = torch.linspace(0, 1, tracer.n_steps).numpy()[k]
+        z = lo + t * (hi - lo)
+        pts = ray_o[torch.from_numpy(r).cuda().long()] + ray_d[torch.from_numpy(r).cuda().long()] * torch.from_numpy(z).cuda()[:, None]
+        v = net.sdf(pts)[:, 0].abs().cpu().numpy()
+        assert v.max() < 1e-5, (v.max(), differ.size)
+    assert differ.size <= max(2, rays.size // 40), differ.size
     print(f"{name}: {rays.size} rays in the reference's sampler ({other_side} on the other side of the sphere-tracing "
-          f"threshold here), first-negative index equal on all {int((neg & common).sum())} common rays with one")
+          f"threshold here); first-negative index equal on {int(common.sum()) - differ.size} of {int(common.sum())} "
+          f"common rays; on the other {differ.size} the disputed sample has |sdf| <= "
+          f"{(v.max() if differ.size else 0.0):.1e} (its sign is round-off)")
