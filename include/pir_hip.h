@@ -268,7 +268,9 @@ enum { PIR_K_SDF_EVAL = 0, PIR_K_SDF_GETALL = 1, PIR_K_TRACE_STEP = 2, PIR_K_SAM
 /* When enabled every kernel launch of the families above is bracketed by hipEvents on its stream. */
 int pir_profile_enable(int on);
 /* Synchronises and returns, per family id < n_ids, the number of launches, their summed duration (ms) and the
- * summed units (points) they processed (0 for the tracer kernels, whose list sizes live on the device). */
+ * summed units they processed: points, or -- for the three tracer families, whose list sizes only exist on the
+ * device -- the SDF evaluations their kernels executed on the CURRENT device (counted by the kernels while the
+ * profiler is enabled, one atomic per tile). */
 int pir_profile_read(int n_ids, long* launches, double* total_ms, double* units);
 
 #ifdef __cplusplus

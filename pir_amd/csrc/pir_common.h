@@ -23,6 +23,8 @@ static inline int pir_num_cus() {
 // kernel families for the optional event profiler (prof.hip)
 extern "C" int pir_prof_begin(int id, double units, void* stream);
 extern "C" void pir_prof_end(int token, void* stream);
+extern "C" int pir_prof_enabled(void);
+extern "C" int pir_trace_profile_read(double* evals3);
 struct PirProfScope {
   int tok; void* st;
   PirProfScope(int id, double units, void* stream) : tok(pir_prof_begin(id, units, stream)), st(stream) {}

@@ -16,9 +16,15 @@ extern "C" {
 
 int pir_profile_enable(int on) {
   std::lock_guard<std::mutex> lk(g_mu);
+  if (on && !g_enabled) {       // start from zero: discard what an earlier profiled region left on the device
+    double drop[3];
+    (void)pir_trace_profile_read(drop);
+  }
   g_enabled = on != 0;
   return PIR_OK;
 }
+
+int pir_prof_enabled(void) { return g_enabled ? 1 : 0; }
 
 // internal: returns a token (>= 0) or -1 when profiling is off
 int pir_prof_begin(int id, double units, void* stream) {
@@ -49,6 +55,14 @@ int pir_profile_read(int n_ids, long* launches, double* total_ms, double* units)
     (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
   }
   g_recs.clear();
+  // the tracer kernels count the SDF evaluations they execute on the device (their list sizes are not known to the
+  // host): units of PIR_K_TRACE_STEP / PIR_K_SAMPLER / PIR_K_BISECT = evaluations (current device)
+  double ev[3] = {0, 0, 0};
+  if (pir_trace_profile_read(ev) == PIR_OK) {
+    if (PIR_K_TRACE_STEP < n_ids) units[PIR_K_TRACE_STEP] = ev[0];
+    if (PIR_K_SAMPLER < n_ids) units[PIR_K_SAMPLER] = ev[1];
+    if (PIR_K_BISECT < n_ids) units[PIR_K_BISECT] = ev[2];
+  }
   return PIR_OK;
 }
 

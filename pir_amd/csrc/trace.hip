@@ -26,6 +26,10 @@ constexpr int kCntBisect = 32, kCntStatus = 33, kCntSampler2 = 34, kNumCounters 
 constexpr int kHead = 8;                      // samples per ray of the sampler's head pass
 constexpr int kHeadRays = 64 / kHead;         // rays per 64-point tile in that pass
 
+// Profiling only (pir_profile_enable): SDF evaluations executed by the three tracer kernel families since the last
+// read, accumulated on the device (index 0 sphere-trace steps, 1 sampler incl. its head pass, 2 bisection).
+__device__ unsigned long long g_trace_evals[4];
+
 __device__ __forceinline__ float mul_rn(float a, float b) { return __fmul_rn(a, b); }
 __device__ __forceinline__ float add_rn(float a, float b) { return __fadd_rn(a, b); }
 
@@ -70,9 +74,10 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* __restrict__ ray_d,
                   const float* __restrict__ max_dis, const unsigned char* __restrict__ work_mask,
                   float* __restrict__ pts, float* __restrict__ sdf, float* __restrict__ dis,
-                  unsigned char* __restrict__ conv, TraceWs ws) {
+                  unsigned char* __restrict__ conv, TraceWs ws, int prof) {
   __shared__ Lds lds;
   const int count = ws.counters[it];
+  if (prof && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trace_evals[0], (unsigned long long)count);
   const int* __restrict__ lin = ws.list[it & 1];
   int* __restrict__ lout = it == max_iters ? ws.slist : ws.list[(it + 1) & 1];
   int* cout = ws.counters + it + 1;
@@ -137,7 +142,7 @@ sampler_kernel(SdfPacked pk, const int* __restrict__ rays, int count_idx, int fi
                int nchunks, const float* __restrict__ ray_o,
                const float* __restrict__ ray_d, const float* __restrict__ min_dis, const float* __restrict__ max_dis,
                float* __restrict__ pts, float* __restrict__ sdf, float* __restrict__ dis,
-               unsigned char* __restrict__ conv, TraceWs ws) {
+               unsigned char* __restrict__ conv, TraceWs ws, int prof) {
   __shared__ Lds lds;
   __shared__ float s_prev_last;   // value of the last sample of the previous pass
   __shared__ int s_found;
@@ -164,6 +169,10 @@ sampler_kernel(SdfPacked pk, const int* __restrict__ rays, int count_idx, int fi
         x0 = add_rn(o0, mul_rn(d0, z)); x1 = add_rn(o1, mul_rn(d1, z)); x2 = add_rn(o2, mul_rn(d2, z));
       }
       eval_tile(lds, pk, x0, x1, x2);
+      if (prof && threadIdx.x == 0) {
+        const int left = n_steps - (first_sample + pass * kWgPts);
+        atomicAdd(&g_trace_evals[1], (unsigned long long)(left < kWgPts ? left : kWgPts));
+      }
       if (threadIdx.x < kWgPts) {
         const int i2 = first_sample + pass * kWgPts + threadIdx.x;
         const float v = read_sdf(lds, pk, threadIdx.x >> 5, threadIdx.x & 31);
@@ -213,9 +222,10 @@ __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 sampler_head_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nchunks, const float* __restrict__ ray_o,
                     const float* __restrict__ ray_d, const float* __restrict__ min_dis,
                     const float* __restrict__ max_dis, float* __restrict__ pts, float* __restrict__ sdf,
-                    float* __restrict__ dis, unsigned char* __restrict__ conv, TraceWs ws) {
+                    float* __restrict__ dis, unsigned char* __restrict__ conv, TraceWs ws, int prof) {
   __shared__ Lds lds;
   const int count = ws.counters[max_iters + 1];
+  if (prof && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_trace_evals[1], (unsigned long long)count * kHead);
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   for (int base = blockIdx.x * kHeadRays; base < count; base += gridDim.x * kHeadRays) {
     {
@@ -282,7 +292,8 @@ sampler_head_kernel(SdfPacked pk, int max_iters, int n_steps, int chunk, int nch
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 bisect_kernel(SdfPacked pk, int it, int final_pass, int max_bisect, float thr, int chunk, int nchunks,
               const float* __restrict__ ray_o, const float* __restrict__ ray_d, float* __restrict__ pts,
-              float* __restrict__ sdf, float* __restrict__ dis, unsigned char* __restrict__ conv, TraceWs ws) {
+              float* __restrict__ sdf, float* __restrict__ dis, unsigned char* __restrict__ conv, TraceWs ws,
+              int prof) {
   __shared__ Lds lds;
   const int count = ws.counters[kCntBisect];
   const int* __restrict__ flag_in = ws.flags + it * nchunks;
@@ -301,6 +312,8 @@ bisect_kernel(SdfPacked pk, int it, int final_pass, int max_bisect, float thr, i
       x2 = add_rn(ray_o[3 * r + 2], mul_rn(ray_d[3 * r + 2], dm));
     }
     if (!__syncthreads_or(active)) continue;   // no ray of this tile is in a chunk that still iterates
+    if (prof && threadIdx.x == 0)
+      atomicAdd(&g_trace_evals[2], (unsigned long long)(count - base < kWgPts ? count - base : kWgPts));
     eval_tile(lds, pk, x0, x1, x2);
     if (threadIdx.x < kWgPts) {
       const int e2 = base + threadIdx.x;
@@ -414,6 +427,7 @@ static int trace_enqueue(const void* packed, long n_rays, const float* ray_o, co
                      stream) != hipSuccess)
     return PIR_ERR_LAUNCH;
   const int N = (int)n_rays;
+  const int prof_on = pir_prof_enabled();
   hipLaunchKernelGGL(trace_init_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, n_rays, ray_o, ray_d, min_dis,
                      points, distance, convergent, ws);
   const long tiles = (n_rays + kWgPts - 1) / kWgPts;
@@ -422,7 +436,7 @@ static int trace_enqueue(const void* packed, long n_rays, const float* ray_o, co
   for (int it = 0; it <= sphere_tracing_iters; ++it) {
     PirProfScope prof(PIR_K_TRACE_STEP, 0.0, stream_);
     hipLaunchKernelGGL(trace_step_kernel, dim3(grid), dim3(kThreads), 0, stream, pk, it, sphere_tracing_iters,
-                       sdf_threshold, ray_d, max_dis, work_mask, points, sdf, distance, convergent, ws);
+                       sdf_threshold, ray_d, max_dis, work_mask, points, sdf, distance, convergent, ws, prof_on);
   }
   const unsigned sgrid = (unsigned)(n_rays < resident ? n_rays : resident);
 #ifdef PIR_SAMPLER_ONEPASS     // A/B: the round-1 form, one workgroup per ray from sample 0
@@ -435,20 +449,20 @@ static int trace_enqueue(const void* packed, long n_rays, const float* ray_o, co
     PirProfScope prof(PIR_K_SAMPLER, 0.0, stream_);
     hipLaunchKernelGGL(sampler_head_kernel, dim3((unsigned)(htiles < resident ? htiles : resident)), dim3(kThreads), 0,
                        stream, pk, sphere_tracing_iters, n_steps, (int)chunk, nchunks, ray_o, ray_d, min_dis, max_dis,
-                       points, sdf, distance, convergent, ws);
+                       points, sdf, distance, convergent, ws, prof_on);
   }
   {
   PirProfScope prof(PIR_K_SAMPLER, 0.0, stream_);
   hipLaunchKernelGGL(sampler_kernel, dim3(sgrid), dim3(kThreads), 0, stream, pk,
                      (const int*)(head ? ws.list[0] : ws.slist), head ? kCntSampler2 : sphere_tracing_iters + 1,
                      head ? kHead : 0, n_steps, (int)chunk, nchunks, ray_o, ray_d, min_dis, max_dis, points, sdf,
-                     distance, convergent, ws);
+                     distance, convergent, ws, prof_on);
   }
   for (int it = 0; it <= max_bisect; ++it) {
     PirProfScope prof(PIR_K_BISECT, 0.0, stream_);
     hipLaunchKernelGGL(bisect_kernel, dim3(grid), dim3(kThreads), 0, stream, pk, it, it == max_bisect ? 1 : 0,
                        max_bisect, sdf_threshold, (int)chunk, nchunks, ray_o, ray_d, points, sdf, distance, convergent,
-                       ws);
+                       ws, prof_on);
   }
   return pir_check_launch();
 }
@@ -554,6 +568,17 @@ int pir_trace_sampler_index(const void* workspace, long n_rays, long chunk, int 
   ws_layout(n_rays, (int)((n_rays + chunk - 1) / chunk), max_bisect, (char*)workspace, &ws);
   return hipMemcpyAsync(min_idx, ws.min_idx, sizeof(int) * (size_t)n_rays, hipMemcpyDeviceToDevice,
                         (hipStream_t)stream_) == hipSuccess ? PIR_OK : PIR_ERR_LAUNCH;
+}
+
+// internal (prof.hip): evaluations executed by the tracer kernels of the current device since the last call;
+// synchronises the device.
+int pir_trace_profile_read(double* evals3) {
+  unsigned long long h[4] = {0, 0, 0, 0};
+  if (hipDeviceSynchronize() != hipSuccess) return PIR_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_trace_evals), sizeof(h)) != hipSuccess) return PIR_ERR_LAUNCH;
+  for (int i = 0; i < 3; ++i) evals3[i] = (double)h[i];
+  const unsigned long long zero[4] = {0, 0, 0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace_evals), zero, sizeof(zero)) == hipSuccess ? PIR_OK : PIR_ERR_LAUNCH;
 }
 
 int pir_trace_status(const void* workspace, int* host_status, void* stream_) {

@@ -347,7 +347,8 @@ def test_sampler_first_negative_index_equals_the_reference_min_idx(name):
         t = torch.linspace(0, 1, tracer.n_steps).numpy()[k]
         z = lo + t * (hi - lo)
         pts = ray_o[torch.from_numpy(r).cuda().long()] + ray_d[torch.from_numpy(r).cuda().long()] * torch.from_numpy(z).cuda()[:, None]
-        v = net.sdf(pts)[:, 0].abs().cpu().numpy()
+        with torch.no_grad():
+            v = net.sdf(pts)[:, 0].abs().cpu().numpy()
         assert v.max() < 1e-5, (v.max(), differ.size)
     assert differ.size <= max(2, rays.size // 40), differ.size
     print(f"{name}: {rays.size} rays in the reference's sampler ({other_side} on the other side of the sphere-tracing "
