@@ -278,7 +278,7 @@ def main():
     # scaled to this run's points per launch.  None when no PMC pass exists for that kernel.
     try:
         pmc = {}
-        for fn in ("r01_pmc_traffic.json", "r02_pmc_traffic.json"):      # the newest pass of each kernel wins
+        for fn in ("r01_pmc_traffic.json", "r02_pmc_traffic.json", "r03_pmc_traffic.json"):   # the newest pass of each kernel wins
             path = os.path.join(ROOT, "profiles", fn)
             if os.path.exists(path):
                 pmc.update(json.load(open(path)))
@@ -290,14 +290,31 @@ def main():
     # matrix-pipe busy share and effective clock of the same kernel from the committed PMC pass
     # (profiles/r02_mfma_util.json: SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE; tools/profile_mfma.sh)
     try:
-        mu = json.load(open(os.path.join(ROOT, "profiles", "r02_mfma_util.json")))
+        mu = {}
+        for fn in ("r02_mfma_util.json", "r03_mfma_util.json"):
+            path = os.path.join(ROOT, "profiles", fn)
+            if os.path.exists(path):
+                mu.update(json.load(open(path)))
         if roofline and names[dom] in mu:
             roofline["mfma_busy_share_pmc"] = mu[names[dom]]["mfma_busy_share_of_simd_cycles"]
             roofline["effective_clock_GHz_pmc"] = mu[names[dom]]["effective_clock_GHz"]
     except (OSError, ValueError, KeyError):
         pass
-    breakdown = {names[i]: {"launches": int(launches[i]), "ms_per_step": round(total_ms[i] / args.steps, 3)}
-                 for i in range(nk) if launches[i]}
+    # per-family achieved rate: algorithmic FLOP per unit x units / HIP-event time.  Units are points, or -- for the three
+    # tracer families -- the SDF evaluations their kernels executed (counted on the device).  wgrad covers the SDF
+    # layers' products (2 x forward per point) plus the material networks' (not separated: no rate given).
+    flop_per_unit = {0: FWD_FLOP_SDF, 1: 2 * FWD_FLOP_SDF, 2: FWD_FLOP_SDF, 3: FWD_FLOP_SDF, 4: FWD_FLOP_SDF,
+                     5: 2 * FWD_FLOP_SDF, 9: FWD_FLOP, 10: FWD_FLOP + FWD_FLOP_SDF}
+    breakdown = {}
+    for i in range(nk):
+        if not launches[i]:
+            continue
+        row = {"launches": int(launches[i]), "ms_per_step": round(total_ms[i] / args.steps, 3)}
+        if i in flop_per_unit and units[i] > 0 and total_ms[i] > 0:
+            tf = flop_per_unit[i] * units[i] / (total_ms[i] * 1e-3) / 1e12
+            row.update({"units_per_step": round(units[i] / args.steps, 1), "flop_per_unit": flop_per_unit[i],
+                        "achieved_TFLOPs": round(tf, 2), "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA, 4)})
+        breakdown[names[i]] = row
 
     # the workload must be the same at every step (frozen scene) and every hit point converged
     if not torch.equal(info["hits"], info["hits_first"]):

@@ -57,14 +57,21 @@ __device__ __forceinline__ float smith_g1(float c, float a) {
   return 2.0f / (1.0f + hypotf(rt, 1.0f));
 }
 
-// x ** 0.25 as torch computes it for fp32 tensors on the CPU the fixtures come from (a <= 1 ulp vectorised pow):
-// the correctly rounded value, obtained in double (two exact-rounded square roots, then one rounding to float).
-// The bare powf differs from it by an ulp on a few inputs, and an ulp decides the bin when w * 100 sits on an integer.
-__device__ __forceinline__ float pow_quarter(float x) {
-#ifdef PIR_GGX_POWF      // A/B: the round-2 form
-  return powf(x, 0.25f);
+// floor(fl(fl(x ** 0.25) * scale)) with x ** 0.25 as torch computes it for fp32 tensors on the CPU the fixtures come
+// from (a <= 1 ulp vectorised pow, in practice the correctly rounded value).  powf is within 2 ulp of that, which can
+// only move the result when w * scale sits within ~2.4e-5 of an integer; those points (about 2 in 1000) take the
+// exact path: x ** 0.25 correctly rounded through double (two correctly rounded square roots, one rounding to float).
+__device__ __forceinline__ long quarter_bin(float x, float scale) {
+#ifdef PIR_GGX_POWF      // A/B: the round-2 form (bare powf: 0.2 % of the bins one off)
+  return (long)floorf(powf(x, 0.25f) * scale);
 #else
-  return (float)sqrt(sqrt((double)x));
+  float t = powf(x, 0.25f) * scale;
+  float fl = floorf(t);
+  if (t - fl < 1e-3f || fl + 1.0f - t < 1e-3f) {
+    t = (float)sqrt(sqrt((double)x)) * scale;
+    fl = floorf(t);
+  }
+  return (long)fl;
 #endif
 }
 
@@ -72,10 +79,9 @@ __device__ __forceinline__ float pow_quarter(float x) {
 // ty = floor((alpha / 4)^0.25 * 50), index = ty * 100 + tx clamped to the table; the 50-entry table uses ty clamped.
 __device__ __forceinline__ void ggx_table_indices(float a, float ci, float co, const GgxTables& tb, long& ii, long& io,
                                                   long& id) {
-  const float wa = pow_quarter(a / 4.0f);
-  const long ty = (long)floorf(wa * 50.0f);
-  ii = ty * 100 + (long)floorf(pow_quarter(ci) * 100.0f);
-  io = ty * 100 + (long)floorf(pow_quarter(co) * 100.0f);
+  const long ty = quarter_bin(a / 4.0f, 50.0f);
+  ii = ty * 100 + quarter_bin(ci, 100.0f);
+  io = ty * 100 + quarter_bin(co, 100.0f);
   ii = ii < 0 ? 0 : (ii > tb.n_rough - 1 ? tb.n_rough - 1 : ii);
   io = io < 0 ? 0 : (io > tb.n_rough - 1 ? tb.n_rough - 1 : io);
   id = ty < 0 ? 0 : (ty > tb.n_diff - 1 ? tb.n_diff - 1 : ty);
@@ -158,6 +164,70 @@ ggx_forward_kernel(long P, const float* __restrict__ light, int light_rgb, int e
     stage_out3(out_s, s[1], base, P);
     stage_out3(out_rgb, s[2], base, P);
     __syncthreads();
+  }
+}
+
+// Forward without LDS: a thread owns FOUR consecutive points, i.e. 12 consecutive floats of every [P,3] array = three
+// 16-byte loads per array straight into registers (17 independent loads in flight per thread, no barrier, no
+// load -> barrier -> compute -> barrier -> store phases).  The last P % 4 points are done by scalar accesses.
+__device__ __forceinline__ void ggx_point_out(const GgxPoint& p, const float* kd, const float* ks, float* od, float* os,
+                                              float* orgb) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    od[c] = p.I[c] * kd[c] * p.Kd;
+    os[c] = p.I[c] * ks[c] * p.Ks;
+    orgb[c] = od[c] + os[c];
+  }
+}
+
+__global__ void __launch_bounds__(kGgxBlock)
+ggx_forward_v4_kernel(long P, const float* __restrict__ light, int light_rgb, int edr, const float* __restrict__ dist,
+                      const float* __restrict__ normal, const float* __restrict__ ldir, const float* __restrict__ vdir,
+                      const float* __restrict__ kd, const float* __restrict__ ks, const float* __restrict__ alpha,
+                      GgxTables tb, float* __restrict__ out_d, float* __restrict__ out_s, float* __restrict__ out_rgb) {
+  const long nquad = P >> 2;
+  const float light0 = light_rgb ? 0.f : light[0];
+  for (long q = (long)blockIdx.x * kGgxBlock + threadIdx.x; q < nquad; q += (long)gridDim.x * kGgxBlock) {
+    union V12 { f4 v[3]; float f[12]; };
+    V12 n, l, v, a_kd, a_ks, lt, od, os, orgb;
+    union V4 { f4 v; float f[4]; } d4, al4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      n.v[k] = reinterpret_cast<const f4*>(normal)[3 * q + k];
+      l.v[k] = reinterpret_cast<const f4*>(ldir)[3 * q + k];
+      v.v[k] = reinterpret_cast<const f4*>(vdir)[3 * q + k];
+      a_kd.v[k] = reinterpret_cast<const f4*>(kd)[3 * q + k];
+      a_ks.v[k] = reinterpret_cast<const f4*>(ks)[3 * q + k];
+      if (light_rgb) lt.v[k] = reinterpret_cast<const f4*>(light)[3 * q + k];
+    }
+    d4.v = reinterpret_cast<const f4*>(dist)[q];
+    al4.v = reinterpret_cast<const f4*>(alpha)[q];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float nn[3] = {n.f[3 * j], n.f[3 * j + 1], n.f[3 * j + 2]};
+      const float ll[3] = {l.f[3 * j], l.f[3 * j + 1], l.f[3 * j + 2]};
+      const float vv[3] = {v.f[3 * j], v.f[3 * j + 1], v.f[3 * j + 2]};
+      GgxPoint p;
+      ggx_eval(p, light_rgb ? &lt.f[3 * j] : &light0, light_rgb, edr, d4.f[j], nn, ll, vv, al4.f[j], tb);
+      ggx_point_out(p, &a_kd.f[3 * j], &a_ks.f[3 * j], &od.f[3 * j], &os.f[3 * j], &orgb.f[3 * j]);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      reinterpret_cast<f4*>(out_d)[3 * q + k] = od.v[k];
+      reinterpret_cast<f4*>(out_s)[3 * q + k] = os.v[k];
+      reinterpret_cast<f4*>(out_rgb)[3 * q + k] = orgb.v[k];
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (P & 3)) {
+    const long i = 4 * nquad + threadIdx.x;
+    const float nn[3] = {normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]};
+    const float ll[3] = {ldir[3 * i], ldir[3 * i + 1], ldir[3 * i + 2]};
+    const float vv[3] = {vdir[3 * i], vdir[3 * i + 1], vdir[3 * i + 2]};
+    const float lrgb[3] = {light_rgb ? light[3 * i] : light0, light_rgb ? light[3 * i + 1] : light0,
+                           light_rgb ? light[3 * i + 2] : light0};
+    GgxPoint p;
+    ggx_eval(p, lrgb, 1, edr, dist[i], nn, ll, vv, alpha[i], tb);
+    ggx_point_out(p, kd + 3 * i, ks + 3 * i, out_d + 3 * i, out_s + 3 * i, out_rgb + 3 * i);
   }
 }
 
@@ -287,6 +357,11 @@ ggx_backward_kernel(long P, const float* __restrict__ light, int light_rgb, int 
   }
 }
 
+template <typename... Ts>
+static bool ggx_aligned16(const Ts*... ptrs) {
+  return (((reinterpret_cast<uintptr_t>(ptrs)) | ...) & 15) == 0;
+}
+
 static unsigned ggx_grid(long P) {
   long blocks = (P + kGgxBlock - 1) / kGgxBlock;
   long cap = 8L * pir_num_cus();
@@ -337,6 +412,16 @@ int pir_ggx_forward(long P, const float* light, int light_is_rgb, int direct_rad
     return PIR_ERR_ARG;
   GgxTables tb{table_rough, n_rough, table_diff, n_diff};
   PirProfScope prof(PIR_K_GGX_FWD, (double)P, stream);
+#ifndef PIR_GGX_LDS       // A/B: -DPIR_GGX_LDS = the round-1/2 kernel (AoS staged through LDS, one point per thread)
+  if (ggx_aligned16(normal, lightdir, viewdir, kd, ks, out_diffuse, out_specular, out_rgb, distance, alpha) &&
+      (!light_is_rgb || ggx_aligned16(light))) {
+    const long quads = (P + 3) / 4, blocks = (quads + kGgxBlock - 1) / kGgxBlock, cap = 8L * pir_num_cus();
+    hipLaunchKernelGGL(ggx_forward_v4_kernel, dim3((unsigned)(blocks < cap ? blocks : cap)), dim3(kGgxBlock), 0,
+                       (hipStream_t)stream, P, light, light_is_rgb, direct_radiance, distance, normal, lightdir, viewdir,
+                       kd, ks, alpha, tb, out_diffuse, out_specular, out_rgb);
+    return pir_check_launch();
+  }
+#endif
   hipLaunchKernelGGL(ggx_forward_kernel, dim3(ggx_grid(P)), dim3(kGgxBlock), 0, (hipStream_t)stream, P, light,
                      light_is_rgb, direct_radiance, distance, normal, lightdir, viewdir, kd, ks, alpha, tb, out_diffuse,
                      out_specular, out_rgb);

@@ -7,7 +7,7 @@ name=$1; shift
 out=variants/$name
 mkdir -p "$out"
 pids=()
-for f in sdf_eval trace ggx sdf_backward wgrad visibility mlp shade_inputs prof; do
+for f in sdf_eval trace ggx sdf_backward wgrad visibility mlp shade_inputs embed edge_walk prof; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment "$@" -c pir_amd/csrc/$f.hip -o "$out/$f.o" &
   pids+=($!)
 done
