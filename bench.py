@@ -301,10 +301,10 @@ def main():
     except (OSError, ValueError, KeyError):
         pass
     # per-family achieved rate: algorithmic FLOP per unit x units / HIP-event time.  Units are points, or -- for the three
-    # tracer families -- the SDF evaluations their kernels executed (counted on the device).  wgrad covers the SDF
-    # layers' products (2 x forward per point) plus the material networks' (not separated: no rate given).
+    # tracer families -- the SDF evaluations their kernels executed (counted on the device).  wgrad: the two products
+    # per SDF layer (2 x forward per point; the material networks' weight-gradient GEMMs are timed under their own id).
     flop_per_unit = {0: FWD_FLOP_SDF, 1: 2 * FWD_FLOP_SDF, 2: FWD_FLOP_SDF, 3: FWD_FLOP_SDF, 4: FWD_FLOP_SDF,
-                     5: 2 * FWD_FLOP_SDF, 9: FWD_FLOP, 10: FWD_FLOP + FWD_FLOP_SDF}
+                     5: 2 * FWD_FLOP_SDF, 6: 2 * FWD_FLOP_SDF, 9: FWD_FLOP, 10: FWD_FLOP + FWD_FLOP_SDF}
     breakdown = {}
     for i in range(nk):
         if not launches[i]:

@@ -12,29 +12,36 @@ namespace pir {
 
 constexpr int kEmbBlock = 256;
 
-// one thread per OUTPUT element: coalesced stores, x[p, d] re-read through L1/L2 (12 B per point)
+// one thread per (point, frequency-or-identity block, input dimension): ONE sincosf serves the sin and the cos column
+// (the kernel is bound by the vector ALU, not by HBM: ocml's full-range sinf / cosf cost ~100 instructions each);
+// stores of a wave cover two runs of contiguous columns per row, x[p, d] is re-read through L1/L2 (12 B per point)
 template <bool kTangent>
 __global__ void __launch_bounds__(kEmbBlock)
-embed_out_kernel(long n_out, int D, int L, const float* __restrict__ x, const float* __restrict__ u,
+embed_out_kernel(long n_work, int D, int L, const float* __restrict__ x, const float* __restrict__ u,
                  float* __restrict__ out) {
-  const int W = D * (1 + 2 * L);
-  for (long i = (long)blockIdx.x * kEmbBlock + threadIdx.x; i < n_out; i += (long)gridDim.x * kEmbBlock) {
-    const long p = i / W;
-    const int j = (int)(i - p * W);
-    const int slot = j / D, d = j - slot * D;
+  const int W = D * (1 + 2 * L), B = D * (1 + L);
+  for (long i = (long)blockIdx.x * kEmbBlock + threadIdx.x; i < n_work; i += (long)gridDim.x * kEmbBlock) {
+    const long p = i / B;
+    const int j = (int)(i - p * B);
+    const int blk = j / D, d = j - blk * D;
     const float xv = x[p * D + d];
-    float r;
-    if (slot == 0) {
-      r = kTangent ? u[p * D + d] : xv;
+    float* __restrict__ row = out + p * W;
+    if (blk == 0) {
+      row[d] = kTangent ? u[p * D + d] : xv;
     } else {
-      const int k = (slot - 1) >> 1;
+      const int k = blk - 1;
       const float f = (float)(1u << k);
-      const float a = xv * f;                    // exact: a power-of-two scale
-      const bool is_sin = ((slot - 1) & 1) == 0;
-      if (kTangent) r = (is_sin ? f * cosf(a) : -(f * sinf(a))) * u[p * D + d];
-      else r = is_sin ? sinf(a) : cosf(a);
+      float sn, cs;
+      sincosf(xv * f, &sn, &cs);                 // xv * f is exact: a power-of-two scale
+      if (kTangent) {
+        const float uv = u[p * D + d];
+        row[(1 + 2 * k) * D + d] = (f * cs) * uv;
+        row[(2 + 2 * k) * D + d] = -(f * sn) * uv;
+      } else {
+        row[(1 + 2 * k) * D + d] = sn;
+        row[(2 + 2 * k) * D + d] = cs;
+      }
     }
-    out[i] = r;
   }
 }
 
@@ -80,7 +87,7 @@ int pir_embed_forward(long P, int D, int L, const float* x, float* out, void* st
   if (!emb_args_ok(P, D, L)) return PIR_ERR_ARG;
   if (P == 0) return PIR_OK;
   if (!x || !out) return PIR_ERR_ARG;
-  const long n = P * D * (1 + 2 * L);
+  const long n = P * D * (1 + L);
   hipLaunchKernelGGL(embed_out_kernel<false>, dim3(emb_grid(n)), dim3(kEmbBlock), 0, (hipStream_t)stream, n, D, L, x,
                      (const float*)nullptr, out);
   return pir_check_launch();
@@ -100,7 +107,7 @@ int pir_embed_tangent(long P, int D, int L, const float* x, const float* u, floa
   if (!emb_args_ok(P, D, L)) return PIR_ERR_ARG;
   if (P == 0) return PIR_OK;
   if (!x || !u || !out) return PIR_ERR_ARG;
-  const long n = P * D * (1 + 2 * L);
+  const long n = P * D * (1 + L);
   hipLaunchKernelGGL(embed_out_kernel<true>, dim3(emb_grid(n)), dim3(kEmbBlock), 0, (hipStream_t)stream, n, D, L, x, u,
                      out);
   return pir_check_launch();

@@ -56,6 +56,12 @@ def main():
                 lab = label(r["Kernel_Name"])
                 if lab:
                     pmc[ctr][lab].append(float(r["Counter_Value"]) * 1024.0)
+    sq = collections.defaultdict(lambda: collections.defaultdict(list))
+    if len(sys.argv) > 6:
+        for r in read_csv(sys.argv[6], "*counter_collection.csv"):
+            lab = label(r["Kernel_Name"])
+            if lab:
+                sq[lab][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for lab, ds in dur.items():
         name, by, unit = lab
@@ -73,6 +79,15 @@ def main():
             row.update({"hbm_fetch_bytes_corrected": round(2.0 * sum(f) / len(f)), "hbm_write_bytes": round(sum(w) / len(w)),
                         "hbm_bytes_per_unit": round(traffic / units, 1), "traffic_over_algorithmic": round(traffic / alg, 3),
                         "hbm_GBps_by_pmc": round(traffic / avg_ns, 1)})
+        c = {k: sum(v) / len(v) for k, v in sq.get(lab, {}).items()}
+        if c.get("GRBM_GUI_ACTIVE") and c.get("SQ_WAVE_CYCLES"):
+            # gfx9 VALUBusy: vector-ALU issue cycles (counted in quads) per SIMD cycle; GRBM_GUI_ACTIVE sums the 8 XCDs
+            xcd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+            row.update({"valu_busy_share_of_simd_cycles": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / 1024.0 / xcd_cycles, 4),
+                        "valu_insts_per_unit": round(c.get("SQ_INSTS_VALU", 0.0) * 64.0 / units, 1) if c.get("SQ_INSTS_VALU") else None,
+                        "wave_wait_any_share": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
+                        "wave_issue_stall_share": round(c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4),
+                        "wave_active_share": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4)})
         out[name] = row
         print(name, row)
     json.dump(out, open(out_path, "w"), indent=1)
