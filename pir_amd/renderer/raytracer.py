@@ -70,7 +70,7 @@ class RayTracer(nn.Module):
         # <= 3); rounds with nothing left to do are skipped on the device, so the margin is free.  Should the bound
         # ever be hit the kernels raise a status word that is accumulated per device and checked by check_status().
         self.max_bisect = self.bisect_rounds_for(1024.0)
-        self._status = {}      # device index -> int32[1] tensor: OR of the status words of every trace so far
+        self._status = {}      # (device index, stream) -> int32[1] tensor: OR of the status words of every trace there
 
     def bisect_rounds_for(self, span):
         """Rounds after which a bracket of span/(n_steps-1) is below 2*sdf_threshold, plus one; within the C ABI's 1..64."""
@@ -102,9 +102,11 @@ class RayTracer(nn.Module):
                                    _lib.ptr(sdf), _lib.ptr(dis), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()),
                        "pir_trace")
         # accumulate the tracer status word (counter 33 of the workspace header) on the device: no host sync here
-        acc = self._status.get(dev.index)
+        # (one accumulator per stream, like the workspace: traces on two streams never update the same word)
+        key = _lib.stream_key(dev)
+        acc = self._status.get(key)
         if acc is None:
-            acc = self._status[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+            acc = self._status[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         acc.bitwise_or_(ws[:256].view(torch.int32)[33:34])
         return {"convergent_mask": conv.bool().reshape(shp), "points": pts.reshape(*shp, 3),
                 "sdf": sdf.reshape(shp), "distance": dis.reshape(shp)}
@@ -117,11 +119,21 @@ class RayTracer(nn.Module):
         points [n,3], sdf [n], distance [n]; `status`: optional int32 [1] device tensor (1 = bisection bound hit)."""
         net = sdf.sdf_network
         n = min_dis.numel()
+        if n > 65536:
+            raise _lib.PirHipError("forward_static: at most 65 536 rays per call (PIR_ERR_TOO_LARGE)")
         for t, dt in ((ray_o, torch.float32), (ray_d, torch.float32), (min_dis, torch.float32),
                       (max_dis, torch.float32), (work_mask, torch.uint8), (out["convergent_mask"], torch.uint8),
                       (out["points"], torch.float32), (out["sdf"], torch.float32), (out["distance"], torch.float32)):
             assert t.is_cuda and t.is_contiguous() and t.dtype == dt, "forward_static takes contiguous fp32/uint8 CUDA tensors"
-        assert out["points"].numel() == 3 * n and out["sdf"].numel() == n and out["distance"].numel() == n
+        # every buffer must hold exactly n rays: a short one would be read / written out of bounds by the kernels
+        sizes = {"ray_o": (ray_o, 3 * n), "ray_d": (ray_d, 3 * n), "max_dis": (max_dis, n), "work_mask": (work_mask, n),
+                 "out.convergent_mask": (out["convergent_mask"], n), "out.points": (out["points"], 3 * n),
+                 "out.sdf": (out["sdf"], n), "out.distance": (out["distance"], n)}
+        for name, (t, want) in sizes.items():
+            if t.numel() != want:
+                raise ValueError(f"forward_static: {name} has {t.numel()} elements, expected {want} for {n} rays")
+        if status is not None and not (status.is_cuda and status.dtype == torch.int32 and status.numel() >= 1):
+            raise ValueError("forward_static: status must be an int32 CUDA tensor")
         with torch.cuda.device(ray_o.device):
             _lib.check(_lib.lib().pir_trace_static(
                 _lib.ptr(net.packed().buf), n, _lib.ptr(ray_o), _lib.ptr(ray_d), _lib.ptr(min_dis), _lib.ptr(max_dis),
@@ -136,9 +148,11 @@ class RayTracer(nn.Module):
         trace since the last check ran out of bisection rounds, i.e. returned brackets wider than 2*sdf_threshold
         where the reference would have kept halving."""
         bad = []
-        for idx, acc in self._status.items():
-            if device is not None and torch.device(device).index not in (None, idx):
+        want = None if device is None else torch.device(device).index
+        for (idx, _stream), acc in self._status.items():
+            if want not in (None, idx):
                 continue
+            torch.cuda.synchronize(idx)       # a trace still running on ANOTHER stream must have landed its OR
             if int(acc.item()) != 0:
                 bad.append(idx)
             if reset:
@@ -408,6 +422,23 @@ def _closing3x3(depth):
     return x[0, 0]
 
 
+def _fill_holes(results):
+    """raytracer.py:630-640: pixels the tracer missed but whose 3x3 closing of the depth map is > 1e-2 take the
+    closed depth (and the hit point it implies) and join the hit mask.  In place; no host synchronisation (the
+    reference's `.any()` guard only skips work that changes nothing)."""
+    depth = _closing3x3(results["depth"])
+    new_mask = depth > 1e-2
+    update = new_mask & ~results["convergent_mask"]
+    any_update = update.any()             # 0-dim device tensor: selects below without a host read
+    results["depth"] = torch.where(update, depth, results["depth"])
+    results["convergent_mask"] = torch.where(any_update, new_mask, results["convergent_mask"])
+    # as in the reference, distance and points of EVERY pixel are then re-derived from the depth map
+    distance = results["depth"] * results["ray_d_norm"]
+    results["distance"] = torch.where(any_update, distance, results["distance"])
+    results["points"] = torch.where(any_update, results["ray_o"] + results["ray_d"] * distance.unsqueeze(-1),
+                                    results["points"])
+
+
 def _sobel_magnitude(depth):
     """kornia.filters.sobel without kornia: 3x3 Sobel kernels normalised by 8, replicate padding,
     sqrt(gx^2 + gy^2 + 1e-6) (kornia's published algorithm; parity with kornia itself unpinned)."""
@@ -496,14 +527,7 @@ def raytrace_camera(camera, sdf_network, raytracer, max_num_rays=200000, fill_ho
                               _pixel_grid=True)
     results["depth"] = results["depth"] * results["convergent_mask"].float()
     if fill_holes:
-        depth = _closing3x3(results["depth"])
-        new_mask = depth > 1e-2
-        update = new_mask & ~results["convergent_mask"]
-        if update.any():
-            results["depth"][update] = depth[update]
-            results["convergent_mask"] = new_mask
-            results["distance"] = results["depth"] * results["ray_d_norm"]
-            results["points"] = results["ray_o"] + results["ray_d"] * results["distance"].unsqueeze(-1)
+        _fill_holes(results)
     if detect_edges:
         depth_edge_mask = (_sobel_magnitude(results["depth"]) > 1e-2) & results["convergent_mask"]
         results.update(locate_edge_points(camera, results["points"], sdf_network, max_step=16, step_size=1e-3,

@@ -8,11 +8,21 @@ from . import _lib
 
 class UnitNormals(torch.Tensor):
     """Marker type for normals that are already n / (|n| + 1e-10): pir_amd's render_fn does not normalise them again.
-    (A render_fn that does -- the reference's own -- only divides a unit vector by 1 + 1e-10.)"""
+    (A render_fn that does -- the reference's own -- only divides a unit vector by 1 + 1e-10.)  The marker does not
+    survive any torch operation: whatever a caller computes from these normals is a plain Tensor again and is
+    re-normalised by render_fn as the reference does."""
 
     @staticmethod
     def mark(t):
         return t.as_subclass(UnitNormals)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        out = super().__torch_function__(func, types, args, kwargs or {})
+        strip = lambda o: o.as_subclass(torch.Tensor) if isinstance(o, UnitNormals) else o  # noqa: E731
+        if isinstance(out, (tuple, list)):
+            return type(out)(strip(o) for o in out)
+        return strip(out)
 
 
 def _f(t):
@@ -41,6 +51,7 @@ class _ShadeInputs(torch.autograd.Function):
         return p_out, nhat, lightdir, dist
 
     @staticmethod
+    @torch.autograd.function.once_differentiable     # raw kernels below: a second differentiation must raise, not be cut
     def backward(ctx, g_p, g_nhat, g_ld, g_dist):
         pts, nrm, ray_d, org = ctx.saved_tensors
         per_point, want_lightdir, reparam, origin_shape, sdf_shape = ctx.meta

@@ -102,9 +102,9 @@ def test_material_backward_matches_eager(P):
             if b is None:
                 assert a is None or float(a.abs().max()) == 0.0, nm
                 continue
-            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 5e-6, (name, nm)
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, (name, nm)
         for k in gp0:
-            assert rel_err(gp0[k].cpu().numpy(), gp1[k].cpu().numpy()) < 5e-6, (name, k)
+            assert rel_err(gp0[k].cpu().numpy(), gp1[k].cpu().numpy()) < 2e-5, (name, k)
 
 
 def _graph_has(fn, name):
@@ -220,11 +220,11 @@ def test_fused_material_networks_match_reference_fixture():
         (y * torch.from_numpy(d[f"{name}.cw"]).cuda()).sum().backward()
         for nm, t in zip(("pts", "nrm", "geo", "dino"), leaves):
             if f"{name}.g_{nm}" in d.files:
-                assert rel_err(t.grad.cpu().numpy(), d[f"{name}.g_{nm}"]) < 5e-6, (name, nm)
+                assert rel_err(t.grad.cpu().numpy(), d[f"{name}.g_{nm}"]) < 2e-5, (name, nm)
         for k, p in net.named_parameters():
             ref = d[f"{name}.g.{k}"]
             g = p.grad.cpu().numpy()
-            assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 1e-5, (name, k)
+            assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 4e-5, (name, k)
 
 
 def test_mlp_entry_points_reject_bad_arguments():
@@ -319,10 +319,10 @@ def test_blend_network_runs_zero_padded_on_the_fused_kernels():
     (y0, l0, g0), (y1, l1, g1) = res
     assert rel_err(y0.cpu().numpy(), y1.cpu().numpy()) < 2e-5 and rel_err(y_inf.cpu().numpy(), y1.cpu().numpy()) < 2e-5
     for a, b in zip(l0, l1):
-        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 8e-6
     for k in g0:
         assert g0[k].shape == g1[k].shape
-        assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 1e-5, k
+        assert rel_err(g0[k].cpu().numpy(), g1[k].cpu().numpy()) < 4e-5, k
 
 
 def test_dino_double_backward_and_passback_stay_differentiable():

@@ -133,7 +133,7 @@ def test_training_step_full_size_materials_fused_vs_eager():
     for k in ("loss", "img_loss", "eik_loss", "roughrange_loss", "smoothness_loss"):
         assert abs(o0[k] - o1[k]) <= 2e-4 * abs(o1[k]) + 1e-9, (k, o0[k], o1[k])
     errs = {k: rel_err(g0[k], g1[k]) for k in g0}
-    assert float(np.median(list(errs.values()))) < 3e-6 and max(errs.values()) < 1e-5, \
+    assert float(np.median(list(errs.values()))) < 1.2e-5 and max(errs.values()) < 4e-5, \
         sorted(errs.items(), key=lambda kv: -kv[1])[:5]
 
 
@@ -201,3 +201,8 @@ def test_training_trajectory_five_steps_matches_reference():
     out = train_traj_util.run("cuda", loss_tol=1e-3, exact_masks=False, step_tol=(0.06, 0.6))
     print("trajectory:", out)
     assert len(out["losses"]) >= 2      # at least up to the first pixel that stops on the other side of the threshold
+
+
+def test_fill_holes_known_answer_gpu():
+    import fill_holes_util
+    fill_holes_util.check("cuda")

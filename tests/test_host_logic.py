@@ -400,3 +400,8 @@ def test_training_trajectory_five_steps_matches_reference_cpu():
     import train_traj_util
     out = train_traj_util.run("cpu", loss_tol=2e-4)
     assert out["comparable"] and len(out["losses"]) == 5
+
+
+def test_fill_holes_known_answer():
+    import fill_holes_util
+    fill_holes_util.check("cpu")
