@@ -6,6 +6,7 @@
 // ray state arithmetic uses un-contracted mul/add so it rounds like the eager PyTorch ops it replaces.
 #include "sdf_sweeps.cuh"
 #include "pir_common.h"
+#include "host_logic.h"
 #include <mutex>
 
 namespace pir {
@@ -376,26 +377,21 @@ __global__ void camera_rays_kernel(long N, int W, const float* __restrict__ uv /
   dmax[i] = t1 + t2;
 }
 
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-
 static size_t ws_layout(long N, int nchunks, int max_bisect, char* base, TraceWs* ws) {
-  size_t off = 0;
-  auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += align256(bytes); return p; };
-  char* cnt = take(sizeof(int) * kNumCounters + sizeof(int) * (size_t)(max_bisect + 2) * nchunks);
-  char* l0 = take(sizeof(int) * N); char* l1 = take(sizeof(int) * N);
-  char* sl = take(sizeof(int) * N); char* bl = take(sizeof(int) * N);
-  char* a = take(sizeof(float) * N); char* b = take(sizeof(float) * N);
-  char* c = take(sizeof(float) * N); char* d = take(sizeof(float) * N);
-  char* bw = take(N);
-  char* mi = take(sizeof(int) * N);
-  if (ws) {
-    ws->min_idx = (int*)mi;
-    ws->counters = (int*)cnt; ws->flags = (int*)cnt + kNumCounters;
-    ws->list[0] = (int*)l0; ws->list[1] = (int*)l1; ws->slist = (int*)sl; ws->blist = (int*)bl;
-    ws->d_lo = (float*)a; ws->d_hi = (float*)b; ws->f_lo = (float*)c; ws->f_hi = (float*)d; ws->bwork = (unsigned char*)bw;
+  size_t off[pir_host::kTrArrays];
+  const size_t total = pir_host::trace_ws_offsets(N, nchunks, max_bisect, off);
+  if (ws && base) {
+    using namespace pir_host;
+    ws->counters = (int*)(base + off[kTrCounters]); ws->flags = ws->counters + kNumCounters;
+    ws->list[0] = (int*)(base + off[kTrList0]); ws->list[1] = (int*)(base + off[kTrList1]);
+    ws->slist = (int*)(base + off[kTrSList]); ws->blist = (int*)(base + off[kTrBList]);
+    ws->d_lo = (float*)(base + off[kTrDLo]); ws->d_hi = (float*)(base + off[kTrDHi]);
+    ws->f_lo = (float*)(base + off[kTrFLo]); ws->f_hi = (float*)(base + off[kTrFHi]);
+    ws->bwork = (unsigned char*)(base + off[kTrBWork]); ws->min_idx = (int*)(base + off[kTrMinIdx]);
   }
-  return off;
+  return total;
 }
+static_assert(kNumCounters == pir_host::kTraceCounters, "host_logic.h and trace.hip disagree on the header size");
 
 }  // namespace pir
 
@@ -405,9 +401,7 @@ extern "C" {
 
 size_t pir_trace_workspace_bytes(long n_rays, long chunk, int max_bisect) {
   if (n_rays <= 0) return 256;
-  if (chunk <= 0) chunk = n_rays;
-  const int nchunks = (int)((n_rays + chunk - 1) / chunk);
-  return ws_layout(n_rays, nchunks, max_bisect, nullptr, nullptr);
+  return ws_layout(n_rays, pir_host::trace_chunks(n_rays, chunk), max_bisect, nullptr, nullptr);
 }
 
 // Enqueues the whole tracer on `stream` over a workspace laid out by ws_layout at `workspace` (arguments checked by
@@ -467,18 +461,7 @@ static int trace_enqueue(const void* packed, long n_rays, const float* ray_o, co
   return pir_check_launch();
 }
 
-static int trace_check_args(const void* packed, long n_rays, const float* ray_o, const float* ray_d,
-                            const float* min_dis, const float* max_dis, const unsigned char* work_mask,
-                            int sphere_tracing_iters, int n_steps, int max_bisect, const unsigned char* convergent,
-                            const float* points, const float* sdf, const float* distance) {
-  if (n_rays < 0 || n_rays > 0x7fffffffL / 4) return PIR_ERR_ARG;
-  if (n_rays == 0) return PIR_OK;
-  if (!packed || !ray_o || !ray_d || !min_dis || !max_dis || !work_mask || !convergent || !points || !sdf || !distance)
-    return PIR_ERR_ARG;
-  if (sphere_tracing_iters < 0 || sphere_tracing_iters > 30 || n_steps < 2 || max_bisect < 1 || max_bisect > 64)
-    return PIR_ERR_ARG;
-  return PIR_OK;
-}
+using pir_host::trace_check_args;
 
 int pir_trace(const void* packed, long n_rays, const float* ray_o, const float* ray_d, const float* min_dis,
               const float* max_dis, const unsigned char* work_mask, float sdf_threshold, int sphere_tracing_iters,

@@ -7,6 +7,7 @@
 #include "sdf_backward.h"
 #include "wgrad.h"
 #include "pir_common.h"
+#include "host_logic.h"
 
 namespace pir {
 
@@ -483,30 +484,17 @@ int wgrad256_run(const WgJobs& jobs, int n_rows, int n_points, const WgFixed& fx
   // its steps stay bound by the operand fetch even with the fetch two steps ahead; measured optimum of 3..6), half
   // for a single product (the feature rows of lin8); every job gets K slices in proportion, as many as fill one
   // round of the CUs, so that all workgroups finish together.
-  int cost[10], total = 0;
+  int cost[10];
   for (int j = 0; j < jobs.n; ++j) {
 #ifndef PIR_W2_NARROW_COST
 #define PIR_W2_NARROW_COST 5
 #endif
     cost[j] = (jobs.j[j].ldy < kW2Tile ? PIR_W2_NARROW_COST : 10) * (jobs.j[j].X2 ? 2 : 1);
-    total += cost[j];
   }
   const int steps = n_rows / kWgKPts;
   const long slab_cap = (long)kKSplitMax * kMaxJobs * kWgTile * kWgTile / ((long)kW2Tile * kW2Tile);   // slabs that fit
-  long slots = pir_num_cus();
-  if (slots > slab_cap) slots = slab_cap;
   Wg2Split sp;
-  int n_wg = 0;
-  for (int j = 0; j < jobs.n; ++j) {
-    int k = (int)(slots * cost[j] / total);
-    const int kmax = steps / 8 > 0 ? steps / 8 : 1;          // at least 8 K steps per slice
-    if (k > kmax) k = kmax;
-    if (k < 1) k = 1;
-    sp.first[j] = n_wg;
-    n_wg += k;
-  }
-  sp.first[jobs.n] = n_wg;
-  for (int j = jobs.n + 1; j < 12; ++j) sp.first[j] = n_wg;
+  const int n_wg = pir_host::wgrad256_split(jobs.n, cost, steps, pir_num_cus(), slab_cap, sp.first);
   {
     PirProfScope prof(prof_id, (double)n_points, stream_);
     hipLaunchKernelGGL(wgrad256_kernel, dim3(n_wg), dim3(kW2Threads), 0, stream, jobs, sp, n_rows, fx.slabs,
@@ -542,17 +530,7 @@ int wgrad_run(const WgJobs& jobs, int n_rows, int n_points, const WgFixed& fx, c
   if (jobs.n < 1 || jobs.n > kMaxJobs || n_rows < kWgKPts || (n_rows % kWgKPts)) return PIR_ERR_ARG;
   // K slices of >= 8 staged steps each, their number chosen so that the workgroups fill whole rounds of the
   // 2-per-CU resident slots (30 jobs x 64 slices left the last round a quarter empty: -5.5 %)
-  int ksplit = 1;
-  {
-    const int kmax = n_rows / kWgKPts / 8 < kKSplitMax ? n_rows / kWgKPts / 8 : kKSplitMax;
-    const long slots = 2L * pir_num_cus();
-    double best = -1.0;
-    for (int k = 1; k <= kmax; ++k) {
-      const long wgs = (long)jobs.n * k, rounds = (wgs + slots - 1) / slots;
-      const double eff = (double)wgs / (double)(rounds * slots);
-      if (eff >= best - 1e-9) { best = eff; ksplit = k; }   // ties: the finer split
-    }
-  }
+  const int ksplit = pir_host::wgrad128_ksplit(jobs.n, n_rows, kWgKPts, 2L * pir_num_cus(), kKSplitMax);
   {
     PirProfScope prof(prof_id, (double)n_points, stream_);
     hipLaunchKernelGGL(wgrad_kernel, dim3(jobs.n * ksplit), dim3(kWgThreads), 0, stream, jobs, n_rows, ksplit,
@@ -580,10 +558,9 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
   if (M < 0 || !packed || !gw9 || !gb9) return PIR_ERR_ARG;
   if (M == 0) return PIR_OK;
   if (!x || !scratch) return PIR_ERR_ARG;
-  if (scratch_bytes < kFixedBytes + 32 * (size_t)kBwdRowBytes + 256) return PIR_ERR_SCRATCH;
+  const long cap = pir_host::bwd_chunk_cap(scratch_bytes, kFixedBytes, kBwdRowBytes, 262144);
+  if (cap <= 0) return PIR_ERR_SCRATCH;
   hipStream_t stream = (hipStream_t)stream_;
-  long cap = (long)((scratch_bytes - kFixedBytes - 256) / kBwdRowBytes) / 32 * 32;
-  if (cap > 262144) cap = 262144;
   const WgFixed fx = wgrad_carve(scratch);
   float* slabs = fx.slabs;
   float* row0 = fx.row0;

@@ -405,3 +405,22 @@ def test_training_trajectory_five_steps_matches_reference_cpu():
 def test_fill_holes_known_answer():
     import fill_holes_util
     fill_holes_util.check("cpu")
+
+
+def test_host_logic_under_sanitizers(tmp_path):
+    """The host-side arithmetic of the C ABI (tracer workspace layout and argument checks, K-slice assignment of the
+    weight-gradient GEMMs, backward chunk capacity: pir_amd/csrc/host_logic.h, the very code the .hip files include)
+    compiled with g++ -fsanitize=address,undefined and driven over edge-case sizes (sanitizers
+    on the host build only)."""
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "host_logic_test"
+    src = os.path.join(ROOT, "tests", "host", "test_host_logic.cpp")
+    subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-Wall", "-Wextra", "-Werror", "-Wno-comment", src, "-o", str(exe)], check=True, timeout=300)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:verify_asan_link_order=0")
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "host logic ok" in r.stdout, r.stdout + r.stderr
