@@ -4,7 +4,7 @@ tests/golden/composite_fp64.npz holds the same reference code run on the same we
 torch.set_default_dtype(float64) (tools/gen_golden_fp64.py).  Every tensor is judged element-wise as in
 full800_util: `ok` within 1e-4 of the fp32 reference; `ok-fp64` no farther from the fp64 run than 2x the fp32
 reference is on that tensor; `ok-group` no farther than the fp32 reference is on the worst tensor of the same
-network's gradients (and < 1e-3 from fp64); anything else FAILs.
+network's gradients; anything else FAILs.
 
 "The fp32 reference's distance from fp64" of a tensor is the LARGEST over the fixture's own fp32 run and the fp32
 re-runs of the same reference code on 1..8 CPU threads that tools/gen_golden_fp64.py recorded (`noise.<tensor>`): two
@@ -50,7 +50,10 @@ class Adjudicator:
             self.add(f"g.{net_name}.{k}", g if g.shape == ref.shape else g[::8], ref)
 
     def finish(self):
-        ok = verdicts(self.report, slack=SLACK)
+        # hard = inf: in these fixtures the reference's own round-off exceeds 1e-3 on several tensors of a network (up
+        # to 1e-1 on the SDF gradients of next_rows.npz), so "no farther than the reference's worst tensor of the same
+        # network" is the bound, not a fixed 1e-3
+        ok = verdicts(self.report, slack=SLACK, hard=float("inf"))
         print_report(self.report, self.title)
         counts = {}
         for row in self.report:
