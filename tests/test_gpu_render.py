@@ -302,11 +302,17 @@ def test_ggx_table_bins_equal_the_reference_bit_for_bit():
     print("GGX table bins: 0 of", 6 * P, "differ from the reference's")
 
 
+@pytest.mark.parametrize("iters", [0, 16])
 @pytest.mark.parametrize("name", ["trace_crop800", "trace_bumpy64", "trace_std64"])
-def test_sampler_first_negative_index_equals_the_reference_min_idx(name):
-    """The dense sampler's index work (raytracer.py:192-197): for every ray the reference hands to ray_sampler, the
-    first negative sample found by the HIP sampler equals the reference's min_idx (where its min_val < 0), rays
-    without a negative sample report none, and exactly the reference's rays reach the sampler."""
+def test_sampler_first_negative_index_equals_the_reference_min_idx(name, iters):
+    """The dense sampler's index work (raytracer.py:192-197): the first negative sample found by the HIP sampler
+    against the reference's min_idx (where its min_val < 0; rays without a negative sample must report none).
+    iters = 0: no sphere tracing, so every ray enters the sampler with the fixture's own interval [min_dis, max_dis]:
+    identical inputs, the index must be EQUAL except where the disputed sample's |sdf| is round-off (< 1e-5: its sign
+    is undecidable in fp32).  iters = 16 (the default tracer): the same comparison on the rays both tracers hand to the
+    sampler; on the 16x zoomed silhouette crop, grazing rays oscillate around the surface for 16 signed steps and their
+    accumulated distance -- the sampler's interval -- differs between any two fp32 evaluations, so only the count is
+    reported there (the hit mask and depth of that fixture are pinned by the tracer tests)."""
     from pir_amd import _lib
     from pir_amd.renderer import raytracer as rt
     d, ix = load_golden(name + ".npz"), load_golden("indices.npz")
@@ -315,43 +321,41 @@ def test_sampler_first_negative_index_equals_the_reference_min_idx(name):
     ray_o, ray_d, _ = cam.get_rays(cam.get_uv())
     ray_o, ray_d = ray_o.reshape(-1, 3).contiguous(), ray_d.reshape(-1, 3).contiguous()
     n = ray_o.shape[0]
-    tracer = rt.RayTracer()
+    tracer = rt.RayTracer(sphere_tracing_iters=iters)
     res = tracer(rt.SdfCallable(net), ray_o, ray_d, torch.from_numpy(d["min_dis"]).cuda(),
                  torch.from_numpy(d["max_dis"]).cuda(), torch.from_numpy(d["work_mask"]).cuda())
-    assert np.array_equal(res["convergent_mask"].cpu().numpy(), d["convergent_mask"])
+    key = name + (".it0" if iters == 0 else "")
+    ref_conv = ix[key + ".convergent_mask"] if iters == 0 else d["convergent_mask"]
+    assert (res["convergent_mask"].cpu().numpy() != ref_conv).sum() <= (0 if iters else 2)
     ws = rt._trace_ws[_lib.stream_key(ray_o.device)]
     idx = torch.empty(n, dtype=torch.int32, device="cuda")
     assert _lib.lib().pir_trace_sampler_index(_lib.ptr(ws), n, 0, tracer.max_bisect, _lib.ptr(idx), _lib.stream_ptr()) == 0
     idx = idx.cpu().numpy()
-    rays, ref_idx, neg = ix[name + ".sampler_rays"], ix[name + ".min_idx"], ix[name + ".min_val_negative"]
+    rays, ref_idx, neg = ix[key + ".sampler_rays"], ix[key + ".min_idx"], ix[key + ".min_val_negative"]
     in_sampler = np.zeros(n, bool)
     in_sampler[rays] = True
-    # which rays reach the sampler is a float decision (|sdf| > 5e-5 after 16 sphere-tracing steps), not index work: a
-    # ray within rounding of the threshold may fall on the other side; the index is compared on the common rays
+    # which rays reach the sampler is a float decision (|sdf| > 5e-5), not index work
     other_side = int(((idx != -2) != in_sampler).sum())
     assert other_side <= max(2, rays.size // 500), other_side
     common = idx[rays] != -2
     got = idx[rays]
     ref_first = np.where(neg, ref_idx, -1)                  # the reference's first negative sample, -1 = none
     differ = np.nonzero(common & (got != ref_first))[0]
-    # Where the index differs the SIGN of a sample differs, i.e. the SDF at that sample is zero to within fp32
-    # round-off (grazing rays of the 16x zoomed silhouette crop run along the surface): checked sample by sample.
-    # The earlier of the two indices is the disputed sample (one side saw it negative, the other did not).
-    if differ.size:
+    worst = 0.0
+    if differ.size and iters == 0:
+        # identical sampler inputs: the earlier of the two indices is the disputed sample, its |sdf| must be round-off
         r = rays[differ]
-        st_sdf, st_dis = d["st_sdf"].reshape(-1)[r], d["st_dis"].reshape(-1)[r]
-        lo = np.where(st_sdf > 0, st_dis, d["min_dis"].reshape(-1)[r]).astype(np.float32)
-        hi = np.where(st_sdf > 0, d["max_dis"].reshape(-1)[r], st_dis).astype(np.float32)
+        lo, hi = d["min_dis"].reshape(-1)[r].astype(np.float32), d["max_dis"].reshape(-1)[r].astype(np.float32)
         a, b = got[differ].astype(np.int64), ref_first[differ].astype(np.int64)
         k = np.where((a >= 0) & ((b < 0) | (a < b)), a, b)
-        t = torch.linspace(0, 1, tracer.n_steps).numpy()[k]
-        z = lo + t * (hi - lo)
-        pts = ray_o[torch.from_numpy(r).cuda().long()] + ray_d[torch.from_numpy(r).cuda().long()] * torch.from_numpy(z).cuda()[:, None]
+        z = lo + torch.linspace(0, 1, tracer.n_steps).numpy()[k] * (hi - lo)
+        sel = torch.from_numpy(r).cuda().long()
         with torch.no_grad():
-            v = net.sdf(pts)[:, 0].abs().cpu().numpy()
-        assert v.max() < 1e-5, (v.max(), differ.size)
-    assert differ.size <= max(2, rays.size // 40), differ.size
-    print(f"{name}: {rays.size} rays in the reference's sampler ({other_side} on the other side of the sphere-tracing "
-          f"threshold here); first-negative index equal on {int(common.sum()) - differ.size} of {int(common.sum())} "
-          f"common rays; on the other {differ.size} the disputed sample has |sdf| <= "
-          f"{(v.max() if differ.size else 0.0):.1e} (its sign is round-off)")
+            v = net.sdf(ray_o[sel] + ray_d[sel] * torch.from_numpy(z).cuda()[:, None])[:, 0].abs().cpu().numpy()
+        worst = float(v.max())
+        assert worst < 1e-5, (worst, differ.size)
+    if iters == 0 or name != "trace_crop800":
+        assert differ.size <= (max(2, rays.size // 200) if iters == 0 else 0), differ.size
+    print(f"{key}: {rays.size} rays in the reference's sampler ({other_side} on the other side of the threshold here); "
+          f"first-negative index equal on {int(common.sum()) - differ.size} of {int(common.sum())} common rays"
+          + (f"; disputed samples have |sdf| <= {worst:.1e}" if differ.size and iters == 0 else ""))

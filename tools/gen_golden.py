@@ -699,6 +699,30 @@ def main():
             assert ix[f"{stem}.min_idx"].shape == ix[f"{stem}.sampler_rays"].shape
             print(f"indices: {stem}: {len(ix[stem + '.min_idx'])} rays in the sampler, "
                   f"{int(ix[stem + '.min_val_negative'].sum())} with a negative sample")
+            # the same with sphere_tracing_iters = 0: every ray that does not start on the surface goes to the sampler
+            # with the interval [min_dis, max_dis] of the fixture itself, so the sampler's index work is compared on
+            # identical inputs (after 16 sphere-tracing steps a grazing ray's accumulated distance is chaotic in fp32)
+            rec = []
+            torch.min = lambda *a, _r=rec, **k: (_r.append(real_min(*a, **k)) if k.get("dim", None) == -1 else None,
+                                                  real_min(*a, **k))[1]
+            tracer0 = rt.RayTracer(sphere_tracing_iters=0)
+            try:
+                with torch.no_grad():
+                    sdf_fn = lambda x, _n=net: _n(x)[..., 0]  # noqa: E731
+                    st0 = tracer0.sphere_tracing(sdf_fn, ray_o, ray_d, torch.from_numpy(tz["min_dis"]),
+                                                 torch.from_numpy(tz["max_dis"]), torch.from_numpy(tz["work_mask"]))
+                    full0 = tracer0(sdf_fn, ray_o, ray_d, torch.from_numpy(tz["min_dis"]), torch.from_numpy(tz["max_dis"]),
+                                    torch.from_numpy(tz["work_mask"]))
+            finally:
+                torch.min = real_min
+            assert len(rec) == 1, len(rec)
+            ix[f"{stem}.it0.sampler_rays"] = np.nonzero(_np(st0[1]).reshape(-1))[0].astype(np.int32)
+            ix[f"{stem}.it0.min_idx"] = rec[0][1].numpy().astype(np.int32)
+            ix[f"{stem}.it0.min_val_negative"] = (rec[0][0] < 0).numpy()
+            ix[f"{stem}.it0.convergent_mask"] = _np(full0["convergent_mask"])
+            assert ix[f"{stem}.it0.min_idx"].shape == ix[f"{stem}.it0.sampler_rays"].shape
+            print(f"indices: {stem} (no sphere tracing): {len(ix[stem + '.it0.min_idx'])} rays in the sampler, "
+                  f"{int(ix[stem + '.it0.min_val_negative'].sum())} with a negative sample")
         save(os.path.join(out_dir, "indices.npz"), **ix)
 
     # known-answer GGX cases of SURVEY.md Appendix A are asserted directly in the tests.
