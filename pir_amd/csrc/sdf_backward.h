@@ -3,8 +3,22 @@
 
 namespace pir {
 
-// HBM scratch of one chunk of points, every array [chunk_rows][256] fp32 in natural feature order
-// (E / Ed: [chunk_rows][64], the 39 encoding columns in reference order).
+// Layout of the four [chunk_rows][256] operand families in HBM scratch.  1 (default): MFMA FRAGMENT order -- per
+// 32-point tile an image [k-block 0..31][lane 0..63] of float4, lane (h, j) holding features 8 kb + 4 h + 0..3 of point
+// j, i.e. element (row, f) at ((row / 32 * 32 + f / 8) * 64 + (f % 8) / 4 * 32 + row % 32) * 4 + f % 4.  The sweep then
+// stores / re-loads one contiguous 1 KB per wave instruction instead of 32 rows x 32 B, and the weight-gradient GEMM
+// un-permutes on its way into LDS (it stages through registers anyway).  0: natural row-major [row][256] (round 1/2;
+// required by the 128 x 128-tile A/B build of the GEMM).
+#ifndef PIR_BWD_FRAG
+#ifdef PIR_WG_TILE128
+#define PIR_BWD_FRAG 0
+#else
+#define PIR_BWD_FRAG 1
+#endif
+#endif
+
+// HBM scratch of one chunk of points, every array [chunk_rows][256] fp32 (layout above)
+// (E / Ed: [chunk_rows][64], the 39 encoding columns in reference order, always row-major).
 struct BwdScratch {
   float* A_;      // a_l   = softplus(z_l), l = 0..7   (row 217.. of layer 3: the encoding, i.e. the lin4 input)
   float* Ad_;     // tangent of a_l along g_normal     (same convention for layer 3)

@@ -10,7 +10,7 @@
 //     Zb_l  d L / d z_l                     (ordinary backprop + the softplus'' term 100 (1-s) Q_l (z_l-tangent))
 // Two fused sweeps per 32-point tile compute them with the two operand sets of the wave pair sharing every
 // weight fragment:  FT (set 0 = activations, set 1 = tangents, layers 0..7) and GZ (set 0 = Q, set 1 = Zb,
-// layers 8..0).  The four operand families go to HBM scratch in natural [point][256] layout for the
+// layers 8..0).  The four operand families go to HBM scratch (fragment order, sdf_backward.h) for the
 // split-K weight-gradient GEMM in wgrad.hip.  d L / d x comes out of the PE Jacobian at the end of GZ.
 #include "sdf_sweeps.cuh"
 #include "sdf_backward.h"
@@ -18,11 +18,20 @@
 
 namespace pir {
 
+// float4 (features 32 T + 8 g + 4 h + 0..3 of the point in scratch row `row`) of a [rows][256] family; h = lane / 32,
+// row % 32 = lane % 32 for every caller, so in fragment order the 64 lanes of one instruction cover 1 KB contiguously
+__device__ __forceinline__ size_t scratch_off(int row, int T, int g, int h) {
+#if PIR_BWD_FRAG
+  return (((size_t)(row >> 5) * 32 + 4 * T + g) * 64 + 32 * h + (row & 31)) * 4;
+#else
+  return (size_t)row * 256 + 32 * T + 8 * g + 4 * h;
+#endif
+}
 __device__ __forceinline__ void store_nat(float* __restrict__ arr, int row, int T, int g, int h, f32x4 v) {
-  *reinterpret_cast<f32x4*>(arr + (size_t)row * 256 + 32 * T + 8 * g + 4 * h) = v;
+  *reinterpret_cast<f32x4*>(arr + scratch_off(row, T, g, h)) = v;
 }
 __device__ __forceinline__ f32x4 load_nat(const float* __restrict__ arr, int row, int T, int g, int h) {
-  return *reinterpret_cast<const f32x4*>(arr + (size_t)row * 256 + 32 * T + 8 * g + 4 * h);
+  return *reinterpret_cast<const f32x4*>(arr + scratch_off(row, T, g, h));
 }
 
 // value of PE column `col` (reference order) of point j in operand set `set`

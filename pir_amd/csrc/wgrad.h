@@ -20,6 +20,8 @@ struct WgJob {
   int col_off, i_limit;               //   ... for the Y columns i < i_limit
   float scale;
   int bias;                           // 1: this job also produces column sums of X1 (i0 == 0 jobs)
+  int x_frag = 0, y_frag = 0;         // 256 x 256-tile kernel only: X1/X2 resp. Y1/Y2 are in fragment order
+                                      // (sdf_backward.h) instead of row-major; such arrays are 256 wide and padded
 };
 struct WgJobs { WgJob j[kMaxJobs]; int n; };
 struct GradOut { float* w[9]; float* b[9]; };

@@ -231,9 +231,54 @@ wgrad_kernel(WgJobs jobs, int n_rows /* multiple of 32 */, int ksplit, float* __
 
 // row 0 of dW8 and db8[0]:  sum_pts (g_sdf a7 + a7-tangent),  sum_pts g_sdf   -> partial[block][257]
 constexpr int kRow0Blocks = 1024;
+#if PIR_BWD_FRAG
+// A7 / Ad7 in fragment order: wave w owns k-blocks 8w .. 8w+7 (columns 64w .. 64w+63), lane (h, j) reads one float4 =
+// columns 8 kb + 4 h + 0..3 of point j per k-block and tile (1 KB per wave instruction); the 32 points of a tile are
+// summed across lanes at the end.  n_rows = the padded row count (multiple of 32); rows >= chunk_n carry zero tangents.
 __global__ void __launch_bounds__(256)
 row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const float* __restrict__ g_sdf /* chunk-local or null */,
-            int chunk_n, float* __restrict__ partial) {
+            int chunk_n, int n_rows, float* __restrict__ partial) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, j = lane & 31, h = lane >> 5;
+  const int ntiles = n_rows / 32;
+  float s[8][4];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s[k][c] = 0.f;
+  float sg = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row = tile * 32 + j;
+    const float g = (g_sdf && row < chunk_n) ? g_sdf[row] : 0.f;
+    sg += g;
+    const f32x4* __restrict__ a = reinterpret_cast<const f32x4*>(A7) + ((size_t)tile * 32 + 8 * w) * 64 + lane;
+    const f32x4* __restrict__ d = reinterpret_cast<const f32x4*>(Ad7) + ((size_t)tile * 32 + 8 * w) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const f32x4 av = a[k * 64], dv = d[k * 64];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[k][c] += g * av[c] + dv[c];
+    }
+  }
+#pragma unroll
+  for (int m = 16; m >= 1; m >>= 1) {
+    sg += __shfl_xor(sg, m);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[k][c] += __shfl_xor(s[k][c], m);
+  }
+  if (j == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) partial[blockIdx.x * 257 + 64 * w + 8 * k + 4 * h + c] = s[k][c];
+    if (w == 0 && h == 0) partial[blockIdx.x * 257 + 256] = sg;
+  }
+}
+#else
+__global__ void __launch_bounds__(256)
+row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const float* __restrict__ g_sdf /* chunk-local or null */,
+            int chunk_n, int /*n_rows*/, float* __restrict__ partial) {
   const int col = threadIdx.x;
   const int r0 = (int)((long)blockIdx.x * chunk_n / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * chunk_n / gridDim.x);
   float s = 0.f, sg = 0.f;
@@ -257,7 +302,7 @@ row0_kernel(const float* __restrict__ A7, const float* __restrict__ Ad7, const f
   partial[blockIdx.x * 257 + col] = s;
   if (col == 0) partial[blockIdx.x * 257 + 256] = sg;
 }
-
+#endif
 
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(WgJobs jobs, int ksplit, const float* __restrict__ slabs, const float* __restrict__ bias_slabs,
@@ -301,9 +346,22 @@ constexpr int kW2Threads = 512;
 constexpr int kW2Tile = 256;
 
 struct TileRegs2 { f32x4 v[4]; };
-// 32 rows x 256 floats of a [rows][256] array (thread t holds float4 #(q*512 + t), q < 4)
+// LDS image of a 32-point step: Xs[point][256 + 4].  Rows 1 KB apart would make the 32 lanes that un-permute a
+// fragment-order tile (one point each, same column) write to the same banks; the 16-byte pad shifts every row by four
+// banks, so 16 consecutive points cover all 64.  Row-major sources and the MFMA operand reads (32 consecutive columns
+// of one row per half wave) are conflict-free either way, and every row offset stays a compile-time immediate.
+constexpr int kW2Ld = kW2Tile + 4;
+
+// 32 rows x 256 floats of a [rows][256] array (thread t holds float4 #(q*512 + t), q < 4).
+// frag: the array is in fragment order (sdf_backward.h): float4 #idx of the tile image = (k-block idx / 64, lane idx % 64)
 __device__ __forceinline__ void load_tile2(TileRegs2& t, const float* __restrict__ src, int ld, int row0,
-                                           int rows_valid) {
+                                           int rows_valid, int frag) {
+  if (frag) {
+    const f32x4* __restrict__ img = reinterpret_cast<const f32x4*>(src + (size_t)row0 * 256);   // row0 % 32 == 0
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t.v[q] = img[q * kW2Threads + threadIdx.x];
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = q * kW2Threads + threadIdx.x;
@@ -314,11 +372,14 @@ __device__ __forceinline__ void load_tile2(TileRegs2& t, const float* __restrict
     t.v[q] = v;
   }
 }
-__device__ __forceinline__ void store_tile2(float (*dst)[kW2Tile], const TileRegs2& t) {
+__device__ __forceinline__ void store_tile2(float (*dst)[kW2Ld], const TileRegs2& t, int frag) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int idx = q * kW2Threads + threadIdx.x;
-    *reinterpret_cast<f32x4*>(&dst[idx >> 6][4 * (idx & 63)]) = t.v[q];
+    int r, c4;
+    if (frag) { const int kb = idx >> 6, lane = idx & 63; r = lane & 31; c4 = 2 * kb + (lane >> 5); }
+    else { r = idx >> 6; c4 = idx & 63; }
+    *reinterpret_cast<f32x4*>(&dst[r][4 * c4]) = t.v[q];
   }
 }
 
@@ -329,8 +390,8 @@ struct Wg2Split { int first[12]; };
 __global__ void __launch_bounds__(kW2Threads, 2)
 wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float* __restrict__ slabs,
                 float* __restrict__ bias_slabs) {
-  __shared__ float Xs[kWgKPts][kW2Tile];
-  __shared__ float Ys[kWgKPts][kW2Tile];
+  __shared__ float Xs[kWgKPts][kW2Ld];
+  __shared__ float Ys[kWgKPts][kW2Ld];
   int job_id = 0;
   while (job_id + 1 < jobs.n && (int)blockIdx.x >= sp.first[job_id + 1]) ++job_id;
   const int ks = blockIdx.x - sp.first[job_id], ksplit = sp.first[job_id + 1] - sp.first[job_id];
@@ -352,8 +413,8 @@ wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float
   TileRegs2 tx, ty;
   auto fetch_into = [&](int step, TileRegs2& fx_, TileRegs2& fy_) {
     const int prod = step % nprod, row0 = (it0 + step / nprod) * kWgKPts;
-    load_tile2(fx_, prod ? jb.X2 : jb.X1, 256, row0, prod ? -1 : jb.x1_rows);
-    load_tile2(fy_, prod ? jb.Y2 : jb.Y1, jb.ldy, row0, prod ? -1 : jb.y1_rows);
+    load_tile2(fx_, prod ? jb.X2 : jb.X1, 256, row0, prod ? -1 : jb.x1_rows, jb.x_frag);
+    load_tile2(fy_, prod ? jb.Y2 : jb.Y1, jb.ldy, row0, prod ? -1 : jb.y1_rows, jb.y_frag);
   };
   auto bias_rows = [&](int step) {
     if (jb.bias && step % nprod == 0) {
@@ -366,18 +427,19 @@ wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float
     if (nsteps > 0) fetch_into(0, tx, ty);
     for (int step = 0; step < nsteps; ++step) {
       __syncthreads();
-      store_tile2(Xs, tx);
-      store_tile2(Ys, ty);
+      store_tile2(Xs, tx, jb.x_frag);
+      store_tile2(Ys, ty, jb.y_frag);
       __syncthreads();
       if (step + 1 < nsteps) fetch_into(step + 1, tx, ty);
       __builtin_amdgcn_sched_barrier(0);
       bias_rows(step);
 #pragma unroll
       for (int s2 = 0; s2 < kWgKPts / 2; ++s2) {
-        const float a0 = Xs[2 * s2 + kh][64 * wr + lo], a1 = Xs[2 * s2 + kh][64 * wr + 32 + lo];
+        const int kr = 2 * s2 + kh;
+        const float a0 = Xs[kr][64 * wr + lo], a1 = Xs[kr][64 * wr + 32 + lo];
         float b[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = Ys[2 * s2 + kh][128 * wc + 32 * t + lo];
+        for (int t = 0; t < 4; ++t) b[t] = Ys[kr][128 * wc + 32 * t + lo];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[t], acc[0][t], 0, 0, 0);
@@ -393,18 +455,19 @@ wgrad256_kernel(WgJobs jobs, Wg2Split sp, int n_rows /* multiple of 32 */, float
     TileRegs2 ux, uy;
     auto narrow_step = [&](int step, TileRegs2& fx_, TileRegs2& fy_) {
       __syncthreads();
-      store_tile2(Xs, fx_);
-      store_tile2(Ys, fy_);
+      store_tile2(Xs, fx_, jb.x_frag);
+      store_tile2(Ys, fy_, jb.y_frag);
       __syncthreads();
       if (step + 2 < nsteps) fetch_into(step + 2, fx_, fy_);
       __builtin_amdgcn_sched_barrier(0);
       bias_rows(step);
 #pragma unroll
       for (int s2 = 0; s2 < kWgKPts / 2; ++s2) {
-        const float a0 = Xs[2 * s2 + kh][32 * wv + lo];
+        const int kr = 2 * s2 + kh;
+        const float a0 = Xs[kr][32 * wv + lo];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const float bt = Ys[2 * s2 + kh][32 * t + lo];
+          const float bt = Ys[kr][32 * t + lo];
           acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bt, acc[0][t], 0, 0, 0);
         }
       }
@@ -602,6 +665,8 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
         j.layer = l; j.row_off = 0; j.rows = rows[l]; j.cols = cols[l]; j.col_off = 0; j.i_limit = cols[l];
         j.scale = l == 4 ? 0.70710678118654752440f : 1.0f;
         j.bias = 1;
+        j.x_frag = PIR_BWD_FRAG;                  // Zb / Q
+        j.y_frag = l == 0 ? 0 : PIR_BWD_FRAG;     // A / Ad (layer 0: the row-major encoding arrays)
         continue;
       }
       const int ni = l == 0 ? 1 : 2;
@@ -625,6 +690,8 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
         j.X1 = g_feat + (size_t)base * 256; j.X2 = nullptr; j.Y1 = sc.A(7); j.Y2 = nullptr;
         j.ldx = 256; j.ldy = 256; j.x1_rows = n; j.y1_rows = -1; j.o0 = 0; j.i0 = 0;
         j.layer = 8; j.row_off = 1; j.rows = 256; j.cols = 256; j.col_off = 0; j.i_limit = 256; j.scale = 1.0f; j.bias = 1;
+        j.x_frag = 0;                             // the caller's g_feat, row-major
+        j.y_frag = PIR_BWD_FRAG;
       } else {
       for (int ot = 0; ot < 2; ++ot)
         for (int itl = 0; itl < 2; ++itl) {
@@ -640,7 +707,7 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
       if (rc != PIR_OK) return rc;
     }
     hipLaunchKernelGGL(row0_kernel, dim3(kRow0Blocks), dim3(256), 0, stream, sc.A(7), sc.Ad(7),
-                       g_sdf ? g_sdf + base : nullptr, n, row0);
+                       g_sdf ? g_sdf + base : nullptr, n, n_rows, row0);
     if (jobs.n > 0) {
       rc = wgrad_run(jobs, n_rows, n, fx, row0, out, PIR_K_WGRAD, stream_);
     } else {      // row 0 of dW8 / db8[0] alone: the reduction kernel's extra block
