@@ -236,6 +236,74 @@ def test_render_path_row_sharding_gloo_world2(tmp_path):
     assert r.stdout.count("ok") == 2
 
 
+_DP_TRAIN_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch, torch.distributed as dist
+import train_step_util
+from pir_amd import train
+from pir_amd.parallel import FlatGradBucket
+
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.set_num_threads(2)
+d, state = train_step_util.build_state("cpu")
+nets = [state.sdf_network] + [state.color_network_dict[k] for k in sorted(state.color_network_dict)]
+params = [p for m in nets for p in m.parameters()]
+bucket = FlatGradBucket(params)
+local = {}
+
+
+def hook():     # TrainState.grad_hook: between loss.backward() and the optimizer steps
+    local["g"] = [None if p.grad is None else p.grad.clone() for p in params]
+    bucket.all_reduce(average=True)
+
+
+state.grad_hook = hook
+np.random.seed(100 + rank)       # every rank draws its own view and crop ...
+torch.manual_seed(7 + rank)      # ... and its own eikonal samples
+out = train.training_step(state, int(d["global_step"]))
+K = out["camera_crop"].K.clone()
+Ks = [torch.zeros_like(K) for _ in range(world)]
+dist.all_gather(Ks, K)
+assert not torch.equal(Ks[0], Ks[1]), "the two ranks rendered the same patch"
+n_checked = 0
+for p, g in zip(params, local["g"]):
+    have = torch.tensor([0 if g is None else 1])
+    haves = [torch.zeros_like(have) for _ in range(world)]
+    dist.all_gather(haves, have)
+    if sum(int(h) for h in haves) == 0:
+        assert p.grad is None
+        continue
+    mine = torch.zeros_like(p) if g is None else g
+    gs = [torch.zeros_like(p) for _ in range(world)]
+    dist.all_gather(gs, mine)
+    want = sum(gs) / world
+    assert p.grad is not None and torch.allclose(p.grad, want, rtol=1e-6, atol=1e-12), (p.grad - want).abs().max()
+    n_checked += 1
+    after = [torch.zeros_like(p) for _ in range(world)]       # same averaged gradient + same Adam state -> same weights
+    dist.all_gather(after, p.detach())
+    assert torch.equal(after[0], after[1])
+assert n_checked > 50
+dist.destroy_process_group()
+print("ok", rank, n_checked)
+"""
+
+
+def test_training_step_data_parallel_gloo_world2(tmp_path):
+    """The real training step (edges, indirect bounce, shadows, all losses) on two ranks with different patches and
+    FlatGradBucket as TrainState.grad_hook: every parameter ends with the mean of the two local gradients and the
+    replicas stay bit-identical after the optimizer steps."""
+    script = tmp_path / "dp_train_worker.py"
+    script.write_text(_DP_TRAIN_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", OMP_NUM_THREADS="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29547", str(script), ROOT],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") == 2
+
+
 def test_shard_units_cover_views_and_rows():
     from pir_amd.parallel import shard_units, shard_rows
     for n_views, world in ((8, 8), (16, 8), (1, 8), (2, 8), (3, 2), (1, 1)):
