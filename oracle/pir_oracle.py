@@ -223,7 +223,8 @@ class Tracer:
         out_s = torch.zeros_like(min_dis)
         out_d = torch.zeros_like(min_dis)
         score = torch.sign(vals) * torch.arange(n, 0, -1).float().reshape(1, n)
-        best, idx = torch.min(score, dim=-1)  # first negative sample (largest weight among negatives)
+        best, idx = torch.min(score, dim=-1)  # first negative sample (largest weight among negatives)  (:192-197)
+        self.last_min_idx, self.last_min_negative = idx, best < 0.0      # the path's index work, kept for the tests
         found = (best < 0.0) & (idx >= 1)
         if found.any():
             i = idx[found].unsqueeze(-1)
@@ -327,6 +328,15 @@ def _smith_g1(c: Tensor, a: Tensor) -> Tensor:
     return 2.0 / (1.0 + torch.hypot(root, torch.ones_like(root)))
 
 
+def ggx_table_bins(c_i: Tensor, c_o: Tensor, a: Tensor, n_rough: int, n_diff: int):
+    """The shader's integer work (src/renderer/renderer_ggx.py:94-99, :103-104, :115-116): bins of the rough-transmittance
+    table for the incident and the outgoing cosine, and of the diffuse table; cosines and roughness already clamped."""
+    ty = torch.floor((a / 4.0) ** 0.25 * 50).long()
+    ix_i = (ty * 100 + torch.floor(c_i ** 0.25 * 100).long()).clamp(0, n_rough - 1)
+    ix_o = (ty * 100 + torch.floor(c_o ** 0.25 * 100).long()).clamp(0, n_rough - 1)
+    return ix_i, ix_o, ty.clamp(0, n_diff - 1)
+
+
 def ggx_shade(light, distance, normal, lightdir, viewdir, kd, ks, alpha, tables: Tuple[Tensor, Tensor],
               direct_radiance: bool = True) -> Dict[str, Tensor]:
     """GGXColocatedRenderer.forward (src/renderer/renderer_ggx.py:39-127)."""
@@ -343,13 +353,10 @@ def ggx_shade(light, distance, normal, lightdir, viewdir, kd, ks, alpha, tables:
     D = 1.0 / (np.pi * a * a * root * root + 1e-10)
     G = _smith_g1(c_i, a) * _smith_g1(c_o, a)
     spec = inten * ks * _F0 * D * G / (4.0 * c_i + 1e-10)
-    wa = (a / 4.0) ** 0.25
-    ty = torch.floor(wa * 50).long()
-    ix_i = (ty * 100 + torch.floor(c_i ** 0.25 * 100).long()).clamp(0, t_rough.numel() - 1)
-    ix_o = (ty * 100 + torch.floor(c_o ** 0.25 * 100).long()).clamp(0, t_rough.numel() - 1)
+    ix_i, ix_o, ix_d = ggx_table_bins(c_i, c_o, a, t_rough.numel(), t_diff.numel())
     T12 = t_rough[ix_i].clamp(0.0, 1.0)
     T21 = t_rough[ix_o].clamp(0.0, 1.0)
-    Fdr = (1.0 - t_diff[ty.clamp(0, t_diff.numel() - 1)]).clamp(0.0, 1.0)
+    Fdr = (1.0 - t_diff[ix_d]).clamp(0.0, 1.0)
     diff = inten * (kd / (1.0 - Fdr + 1e-10) / np.pi) * c_o * T12 * T21 * (1.0 / (_ETA * _ETA))
     return {"diffuse_rgb": diff, "specular_rgb": spec, "rgb": diff + spec}
 

@@ -311,8 +311,9 @@ def test_sampler_first_negative_index_equals_the_reference_min_idx(name, iters):
     identical inputs, the index must be EQUAL except where the disputed sample's |sdf| is round-off (< 1e-5: its sign
     is undecidable in fp32).  iters = 16 (the default tracer): the same comparison on the rays both tracers hand to the
     sampler; on the 16x zoomed silhouette crop, grazing rays oscillate around the surface for 16 signed steps and their
-    accumulated distance -- the sampler's interval -- differs between any two fp32 evaluations, so only the count is
-    reported there (the hit mask and depth of that fixture are pinned by the tracer tests)."""
+    accumulated distance -- the sampler's interval -- differs between any two fp32 evaluations: the reference run on one
+    CPU thread, or with the network called on slices of 997 rows, disagrees with its own 8-thread run on 44 of 1 848
+    rays there (0 on the two 64 x 64 views).  The bound is twice that self-disagreement (so 0 where it is 0)."""
     from pir_amd import _lib
     from pir_amd.renderer import raytracer as rt
     d, ix = load_golden(name + ".npz"), load_golden("indices.npz")
@@ -354,8 +355,19 @@ def test_sampler_first_negative_index_equals_the_reference_min_idx(name, iters):
             v = net.sdf(ray_o[sel] + ray_d[sel] * torch.from_numpy(z).cuda()[:, None])[:, 0].abs().cpu().numpy()
         worst = float(v.max())
         assert worst < 1e-5, (worst, differ.size)
-    if iters == 0 or name != "trace_crop800":
-        assert differ.size <= (max(2, rays.size // 200) if iters == 0 else 0), differ.size
+    own = 0
+    if iters == 0:
+        assert differ.size <= max(2, rays.size // 200), differ.size
+    else:
+        # yardstick: the reference against ITSELF under two other fp32 evaluation orders (1 CPU thread; the network
+        # called on slices of 997 rows), same rays, same default tracer (tools/gen_golden.py, indices section)
+        ref_map = dict(zip(rays.tolist(), ref_first.tolist()))
+        for alt in ("alt_t1", "alt_rows997"):
+            r2 = ix[f"{key}.{alt}.sampler_rays"]
+            f2 = np.where(ix[f"{key}.{alt}.min_val_negative"], ix[f"{key}.{alt}.min_idx"], -1)
+            own = max(own, sum(ref_map[r] != f for r, f in zip(r2.tolist(), f2.tolist()) if r in ref_map))
+        assert differ.size <= 2 * own, (differ.size, own)     # 0 allowed only where the reference agrees with itself
     print(f"{key}: {rays.size} rays in the reference's sampler ({other_side} on the other side of the threshold here); "
           f"first-negative index equal on {int(common.sum()) - differ.size} of {int(common.sum())} common rays"
-          + (f"; disputed samples have |sdf| <= {worst:.1e}" if differ.size and iters == 0 else ""))
+          + (f"; disputed samples have |sdf| <= {worst:.1e}" if differ.size and iters == 0 else "")
+          + (f"; the reference differs from itself on {own} rays when its fp32 evaluation order changes" if iters else ""))

@@ -699,6 +699,36 @@ def main():
             assert ix[f"{stem}.min_idx"].shape == ix[f"{stem}.sampler_rays"].shape
             print(f"indices: {stem}: {len(ix[stem + '.min_idx'])} rays in the sampler, "
                   f"{int(ix[stem + '.min_val_negative'].sum())} with a negative sample")
+            # the reference against ITSELF under another fp32 evaluation order (1 thread instead of 8; the network
+            # evaluated in slices of 997 rows, which moves rows between GEMM micro-kernels): how many first-negative
+            # indices of the default tracer survive a change of rounding.  The yardstick for the 16-iteration case.
+            for alt, threads, rows in (("alt_t1", 1, None), ("alt_rows997", 8, 997)):
+                torch.set_num_threads(threads)
+                if rows is None:
+                    fn = lambda x, _n=net: _n(x)[..., 0]  # noqa: E731
+                else:
+                    fn = lambda x, _n=net, _r=rows: torch.cat([_n(c)[..., 0] for c in x.split(_r)]) if x.shape[0] else _n(x)[..., 0]  # noqa: E731
+                rec = []
+                torch.min = lambda *a, _r=rec, **k: (_r.append(real_min(*a, **k)) if k.get("dim", None) == -1 else None,
+                                                      real_min(*a, **k))[1]
+                try:
+                    with torch.no_grad():
+                        st = tracer.sphere_tracing(fn, ray_o, ray_d, torch.from_numpy(tz["min_dis"]),
+                                                   torch.from_numpy(tz["max_dis"]), torch.from_numpy(tz["work_mask"]))
+                        tracer(fn, ray_o, ray_d, torch.from_numpy(tz["min_dis"]), torch.from_numpy(tz["max_dis"]),
+                               torch.from_numpy(tz["work_mask"]))
+                finally:
+                    torch.min = real_min
+                    torch.set_num_threads(8)
+                assert len(rec) == 1, len(rec)
+                ix[f"{stem}.{alt}.sampler_rays"] = np.nonzero(_np(st[1]).reshape(-1))[0].astype(np.int32)
+                ix[f"{stem}.{alt}.min_idx"] = rec[0][1].numpy().astype(np.int32)
+                ix[f"{stem}.{alt}.min_val_negative"] = (rec[0][0] < 0).numpy()
+                a = dict(zip(ix[f"{stem}.sampler_rays"].tolist(), np.where(ix[f"{stem}.min_val_negative"], ix[f"{stem}.min_idx"], -1).tolist()))
+                b = dict(zip(ix[f"{stem}.{alt}.sampler_rays"].tolist(), np.where(ix[f"{stem}.{alt}.min_val_negative"], ix[f"{stem}.{alt}.min_idx"], -1).tolist()))
+                both = set(a) & set(b)
+                print(f"indices: {stem} {alt}: sampler sets differ on {len(set(a) ^ set(b))} rays, first-negative index "
+                      f"differs on {sum(a[r] != b[r] for r in both)} of {len(both)} common rays")
             # the same with sphere_tracing_iters = 0: every ray that does not start on the surface goes to the sampler
             # with the interval [min_dis, max_dis] of the fixture itself, so the sampler's index work is compared on
             # identical inputs (after 16 sphere-tracing steps a grazing ray's accumulated distance is chaotic in fp32)
