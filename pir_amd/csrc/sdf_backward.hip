@@ -27,11 +27,37 @@ __device__ __forceinline__ size_t scratch_off(int row, int T, int g, int h) {
   return (size_t)row * 256 + 32 * T + 8 * g + 4 * h;
 #endif
 }
+// PIR_ABL_* : ablation builds for timing only (tools/build_variant.sh); their results are wrong
 __device__ __forceinline__ void store_nat(float* __restrict__ arr, int row, int T, int g, int h, f32x4 v) {
+#ifdef PIR_ABL_NO_A_STORE
+  if (v[0] != 12345.678f) return;
+#endif
+#ifdef PIR_BWD_NT_A
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(arr + scratch_off(row, T, g, h)));
+#else
   *reinterpret_cast<f32x4*>(arr + scratch_off(row, T, g, h)) = v;
+#endif
+}
+// Q / Zb are written once here and read once by the weight-gradient GEMM of a later launch (PIR_BWD_NT_QZ, sdf_backward.h)
+__device__ __forceinline__ void store_nat_stream(float* __restrict__ arr, int row, int T, int g, int h, f32x4 v) {
+#ifdef PIR_ABL_NO_QZ_STORE
+  if (v[0] != 12345.678f) return;
+#endif
+#if PIR_BWD_NT_QZ
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(arr + scratch_off(row, T, g, h)));
+#else
+  store_nat(arr, row, T, g, h, v);
+#endif
 }
 __device__ __forceinline__ f32x4 load_nat(const float* __restrict__ arr, int row, int T, int g, int h) {
+#ifdef PIR_ABL_NO_A_LOAD
+  if (row != -12345) return f32x4{0.001f * T, 0.002f * g, 0.003f * h, 0.004f};
+#endif
+#if PIR_BWD_NT_LD
+  return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(arr + scratch_off(row, T, g, h)));
+#else
   return *reinterpret_cast<const f32x4*>(arr + scratch_off(row, T, g, h));
+#endif
 }
 
 // value of PE column `col` (reference order) of point j in operand set `set`
@@ -172,7 +198,9 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
           store_nat(sc.A(l), row, T, g, h, a);
           store_nat(sc.Ad(l), row, T, g, h, ad);
         }
+#ifndef PIR_BWD_FT_NOSB
         __builtin_amdgcn_sched_barrier(0);   // keep one tile's loads/stores in flight at a time (register pressure)
+#endif
       }
       PIR_PRIO_LO();
       __syncthreads();
@@ -226,16 +254,28 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
           }
           lds.act[0][4 * T + g][lane] = q;
           lds.act[1][4 * T + g][lane] = zb;
-          store_nat(sc.Q(m), row, T, g, h, q);
-          store_nat(sc.Zb(m), row, T, g, h, zb);
+          store_nat_stream(sc.Q(m), row, T, g, h, q);
+          store_nat_stream(sc.Zb(m), row, T, g, h, zb);
         }
+#ifndef PIR_BWD_GZ_NOSB
         __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       PIR_PRIO_LO();
       __syncthreads();
       if (m >= 1) {
+#if PIR_BWD_TOUCH
+        // pull the A / Ad fragments the NEXT epilogue reads (8 KB each per wave, contiguous in fragment order) towards
+        // the L2 while this layer's products run: one dword per 128-byte line
+        const size_t touch = ((size_t)(tile * kTilePts + 8 * w) * 64) * 4 + lane * 32;
+        const float t0 = sc.A(m - 1)[touch], t1 = sc.Ad(m - 1)[touch];
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         zero_acc(acc);
         gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[m], kTPW * w, lds, 0, acc, pre, m >= 2, kRev[m >= 2 ? m - 1 : m]);
+#if PIR_BWD_TOUCH
+        asm volatile("" ::"v"(t0), "v"(t1));
+#endif
         if (m == 4 && w < 2) {
           f32x16 accpe[kSets][1];
           zero_acc(accpe);

@@ -266,6 +266,9 @@ __device__ __forceinline__ float softplus100(float z) {
 }
 // sigma(100 z) recovered from a = softplus100(z): 1 - exp(-100 a)  (exact identity; 1 in the linear branch)
 __device__ __forceinline__ float dsoftplus_from_act(float a) {
+#ifdef PIR_ABLATE_ACT
+  return a;
+#endif
   return 1.f - __builtin_amdgcn_exp2f(a * -144.26950408889634f);
 }
 
@@ -314,6 +317,24 @@ __device__ __forceinline__ void write_pe(Lds& lds, int set, float x0, float x1, 
   }
 }
 
+// Activation spill of get_all (written by the forward sweep, read back once by the reverse sweep of the same tile).
+// PIR_SPILL_NT_ST / PIR_SPILL_NT_LD: non-temporal accesses, so that the stream does not displace the packed weights
+// (2 x 2.1 MB, re-read by every tile) from the 4 MB L2 of the XCD.
+__device__ __forceinline__ void spill_store(f32x4* __restrict__ p, f32x4 v) {
+#ifdef PIR_SPILL_NT_ST
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ f32x4 spill_load(const f32x4* __restrict__ p) {
+#ifdef PIR_SPILL_NT_LD
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 // Hidden-layer epilogue: a = softplus(acc + bias) -> LDS natural region of both sets.
 // Optionally also stores the activations to a private scratch image (float4 per lane, coalesced).
 template <bool STORE>
@@ -332,7 +353,7 @@ __device__ __forceinline__ void epilogue_softplus(Lds& lds, f32x16 (&acc)[kSets]
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[c] = softplus100(acc[s][t][4 * g + c] + b[c]);
         lds.act[s][4 * T + g][lane] = a;
-        if (STORE) scratch[((s * 8 + T) * 4 + g) * 64 + lane] = a;
+        if (STORE) spill_store(scratch + ((s * 8 + T) * 4 + g) * 64 + lane, a);
       }
     }
   }

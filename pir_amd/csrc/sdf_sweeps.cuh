@@ -156,7 +156,7 @@ __device__ __forceinline__ void epilogue_mul_dact(Lds& lds, f32x16 (&acc)[kSets]
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
       for (int s = 0; s < kSets; ++s) {
-        f32x4 a = scratch_layer[((s * 8 + T) * 4 + g) * 64 + lane];
+        f32x4 a = spill_load(scratch_layer + ((s * 8 + T) * 4 + g) * 64 + lane);
         f32x4 q;
 #pragma unroll
         for (int c = 0; c < 4; ++c) q[c] = acc[s][t][4 * g + c] * dsoftplus_from_act(a[c]);

@@ -359,7 +359,11 @@ __device__ __forceinline__ void load_tile2(TileRegs2& t, const float* __restrict
   if (frag) {
     const f32x4* __restrict__ img = reinterpret_cast<const f32x4*>(src + (size_t)row0 * 256);   // row0 % 32 == 0
 #pragma unroll
+#ifdef PIR_WG_NT_LD
+    for (int q = 0; q < 4; ++q) t.v[q] = __builtin_nontemporal_load(&img[q * kW2Threads + threadIdx.x]);   // read once
+#else
     for (int q = 0; q < 4; ++q) t.v[q] = img[q * kW2Threads + threadIdx.x];
+#endif
     return;
   }
 #pragma unroll
