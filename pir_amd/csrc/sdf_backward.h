@@ -44,7 +44,7 @@ struct BwdScratch {
   float* Q_;      // d sdf / d z_l
   float* E;       // positional encoding
   float* Ed;      // its tangent
-  float* pe_tmp;  // per-workgroup parking space of the sweep (2 waves x 32 registers x 64 lanes floats each):
+  float* pe_tmp;  // per-workgroup parking space of the sweep (4 waves x 32 registers x 64 lanes floats each):
                   // the lin4 share of the encoding gradient waits here while layers 3..0 run
   size_t layer_stride;   // floats between consecutive layers of one family (= chunk rows * 256)
   __host__ __device__ float* A(int l) const { return A_ + l * layer_stride; }

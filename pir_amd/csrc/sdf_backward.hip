@@ -16,6 +16,10 @@
 #include "sdf_backward.h"
 #include "pir_common.h"
 
+#ifndef PIR_PE_KSPLIT_BWD
+#define PIR_PE_KSPLIT_BWD PIR_PE_KSPLIT
+#endif
+
 namespace pir {
 
 // float4 (features 32 T + 8 g + 4 h + 0..3 of the point in scratch row `row`) of a [rows][256] family; h = lane / 32,
@@ -230,7 +234,11 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     }
     // gradient w.r.t. the encoding slots = lin4's share (skip connection) + lin0's share.  The first is parked in
     // global memory between the two products instead of occupying 32 registers through layers 3..0.
+#if PIR_PE_KSPLIT_BWD
+    float* pe_park = sc.pe_tmp + ((size_t)blockIdx.x * 4 + w) * (32 * 64) + lane;
+#else
     float* pe_park = sc.pe_tmp + ((size_t)blockIdx.x * 2 + (w & 1)) * (32 * 64) + lane;
+#endif
 #pragma nounroll
     for (int l = 8; l >= 1; --l) {
       // acc = (u_l, y_l): gradients w.r.t. the input of layer l  ->  (q_{l-1}, zb_{l-1})
@@ -276,10 +284,14 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
 #if PIR_BWD_TOUCH
         asm volatile("" ::"v"(t0), "v"(t1));
 #endif
-        if (m == 4 && w < 2) {
+        if (m == 4 && (PIR_PE_KSPLIT_BWD || w < 2)) {
           f32x16 accpe[kSets][1];
           zero_acc(accpe);
+#if PIR_PE_KSPLIT_BWD
+          gemm_phase<1>(pk.mats, pe_khalf(kR4P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
+#else
           gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+#endif
 #pragma unroll
           for (int s2 = 0; s2 < kSets; ++s2)
 #pragma unroll
@@ -290,8 +302,12 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     }
     f32x16 accpe[kSets][1];
     zero_acc(accpe);
-    if (w < 2) {
+    if (PIR_PE_KSPLIT_BWD || w < 2) {
+#if PIR_PE_KSPLIT_BWD
+      gemm_phase<1>(pk.mats, pe_khalf(kR0P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
+#else
       gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);
+#endif
 #pragma unroll
       for (int s2 = 0; s2 < kSets; ++s2)
 #pragma unroll
@@ -301,11 +317,16 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
     // ------------------------------------------------------------------ d L / d x through the encoding
     if (g_x) {
       float xb[3] = {0.f, 0.f, 0.f};
+#if PIR_PE_KSPLIT_BWD
+      if ((w & 1) == 0) pe_xbar<0>(lds, accpe, nb0, nb1, nb2, h, xb);     // linear in accpe: partial sums per K half
+      else pe_xbar<1>(lds, accpe, nb0, nb1, nb2, h, xb);
+#else
       if (w == 0) pe_xbar<0>(lds, accpe, nb0, nb1, nb2, h, xb);
       else if (w == 1) pe_xbar<1>(lds, accpe, nb0, nb1, nb2, h, xb);
+#endif
 #pragma unroll
       for (int c = 0; c < 3; ++c) xb[c] += __shfl_xor(xb[c], 32);
-      if (lane < 32 && w < 2) {
+      if (lane < 32 && (PIR_PE_KSPLIT_BWD || w < 2)) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) lds.red[w][0][lane][1 + c] = xb[c];
       }
@@ -313,7 +334,11 @@ bwd_sweep_kernel(SdfPacked pk, const float* __restrict__ x, const float* __restr
       if (threadIdx.x < kTilePts && tile * kTilePts + (int)threadIdx.x < chunk_n) {
         const long Q = chunk_base + tile * kTilePts + threadIdx.x;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) g_x[3 * Q + c] = lds.red[0][0][threadIdx.x][1 + c] + lds.red[1][0][threadIdx.x][1 + c];
+        for (int c = 0; c < 3; ++c) {
+          float v = lds.red[0][0][threadIdx.x][1 + c] + lds.red[1][0][threadIdx.x][1 + c];
+          if (PIR_PE_KSPLIT_BWD) v += lds.red[2][0][threadIdx.x][1 + c] + lds.red[3][0][threadIdx.x][1 + c];
+          g_x[3 * Q + c] = v;
+        }
       }
     }
     __syncthreads();

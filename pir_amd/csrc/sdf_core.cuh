@@ -86,6 +86,16 @@ constexpr Prod kR1 = {kR2.off + prod_size(kActKB, 8), kActKB, 8};
 constexpr Prod kR0P = {kR1.off + prod_size(kActKB, 8), kActKB, 2};      // PE rows of lin0^T
 constexpr int kPackedF4 = kR0P.off + prod_size(kActKB, 2);              // total f32x4 count
 
+// The two transposed products onto the encoding rows (kR4P, kR0P) have two tiles for four waves.  1 (default): every
+// wave takes one tile over one half of K and the partial results are added where they are consumed; 0: waves 0 and 1
+// run the whole K while waves 2 and 3 wait at the next barrier (rounds 1-2).
+#ifndef PIR_PE_KSPLIT
+#define PIR_PE_KSPLIT 1
+#endif
+__host__ __device__ constexpr Prod pe_khalf(Prod p, int half) {
+  return Prod{p.off + half * (p.nkb / 2) * p.ntiles * kTileKB, p.nkb / 2, p.ntiles};
+}
+
 // vectors appended after the matrices (floats): bias[9][256], w8row[256]
 constexpr int kVecBias = 0;
 constexpr int kVecW8 = 9 * 256;

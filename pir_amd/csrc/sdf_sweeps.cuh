@@ -226,7 +226,11 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
   for (int l = 7; l >= 1; --l) {
     zero_acc(acc);
     gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[l], kTPW * w, lds, 0, acc, pre, l >= 2, kRev[l >= 2 ? l - 1 : l]);
+#if PIR_PE_KSPLIT
+    if (l == 4) gemm_phase<1>(pk.mats, pe_khalf(kR4P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
+#else
     if (l == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+#endif
     PIR_STAMP(7);
     __syncthreads();
     PIR_STAMP(2);
@@ -237,14 +241,21 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
     __syncthreads();
     PIR_STAMP(4);
   }
-  if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
   float n[kSets][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+#if PIR_PE_KSPLIT
+  // the two PE tiles over the two halves of K: wave w = (K half w / 2, tile w % 2); the encoding Jacobian is linear
+  // in the accumulator, so every wave transforms its partial sum and read_normal adds the four
+  gemm_phase<1>(pk.mats, pe_khalf(kR0P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
+  if ((w & 1) == 0) pe_jacobian_t<0>(lds, accpe, n); else pe_jacobian_t<1>(lds, accpe, n);
+#else
+  if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
   if (w == 0) pe_jacobian_t<0>(lds, accpe, n); else if (w == 1) pe_jacobian_t<1>(lds, accpe, n);
+#endif
 #pragma unroll
   for (int s = 0; s < kSets; ++s)
 #pragma unroll
     for (int c = 0; c < 3; ++c) n[s][c] += __shfl_xor(n[s][c], 32);
-  if (lane < 32 && w < 2) {
+  if (lane < 32 && (PIR_PE_KSPLIT || w < 2)) {
 #pragma unroll
     for (int s = 0; s < kSets; ++s)
 #pragma unroll
@@ -252,7 +263,11 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
   }
 }
 __device__ __forceinline__ float read_normal(const Lds& lds, int set, int j, int c) {
+#if PIR_PE_KSPLIT
+  return (lds.red[0][set][j][1 + c] + lds.red[1][set][j][1 + c]) + (lds.red[2][set][j][1 + c] + lds.red[3][set][j][1 + c]);
+#else
   return lds.red[0][set][j][1 + c] + lds.red[1][set][j][1 + c];
+#endif
 }
 
 }  // namespace pir

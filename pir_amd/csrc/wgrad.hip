@@ -641,7 +641,7 @@ int pir_sdf_get_all_backward(const void* packed, const float* x, long M, const f
   sc.Q_ = f; f += 8 * sc.layer_stride;
   sc.E = f; f += cap * 64;
   sc.Ed = f;
-  sc.pe_tmp = slabs;   // the slabs are idle while the sweep runs (stream order): 16 KB per resident workgroup
+  sc.pe_tmp = slabs;   // the slabs are idle while the sweep runs (stream order): 32 KB per resident workgroup
   GradOut out;
   for (int l = 0; l < 9; ++l) { out.w[l] = gw9[l]; out.b[l] = gb9[l]; if (!out.w[l] || !out.b[l]) return PIR_ERR_ARG; }
   static const int rows[9] = {256, 256, 256, kSkipKeep, 256, 256, 256, 256, 257};

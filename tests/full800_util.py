@@ -16,14 +16,19 @@ def elem_err(got, ref, floor=None):
     return float((np.abs(got - ref) / (np.abs(ref) + floor)).max())
 
 
-def judge(name, got, ref32, ref64, report, tol=TOL, slack=2.0, group=None):
+def judge(name, got, ref32, ref64, report, tol=TOL, slack=2.0, group=None, noise=None):
     """Records the three errors of one tensor for `verdicts`: got vs the fp32 reference, got vs the fp64 run of the
     same reference code, the fp32 reference vs fp64.  `group`: tensors that share one upstream (the gradients of
-    one network); defaults to the name's first two dot-separated fields."""
+    one network); defaults to the name's first two dot-separated fields.  `noise`: the largest distance from fp64 the
+    reference's fp32 run reaches under other CPU thread counts (tests/golden/shade_points_noise.npz): one fp32 run is
+    one sample of the reference's round-off, and a ReLU of the material networks that sits on its kink for one hit
+    point flips between two such runs (2 threads vs 8: every SDF gradient moves 10-20x farther from fp64)."""
     floor = np.abs(np.asarray(ref64, np.float64)).mean() + 1e-300
     e32 = elem_err(got, ref32, floor)
     e_got = elem_err(got, ref64, floor)
     e_ref = elem_err(ref32, ref64, floor)
+    if noise is not None:
+        e_ref = max(e_ref, float(noise))
     report.append([name, e32, e_got, e_ref, None, group or ".".join(name.split(".")[:2])])
     return True
 
@@ -56,7 +61,7 @@ def verdicts(report, tol=TOL, slack=2.0, hard=1e-3):
 
 
 def print_report(report, title):
-    print(f"\n{title}: tensor | err vs fp32 ref | err vs fp64 | fp32 ref vs fp64")
+    print(f"\n{title}: tensor | err vs fp32 ref | err vs fp64 | fp32 ref vs fp64 (worst of its re-runs, where given)")
     for name, e32, eg, er, verdict, _ in report:
         print(f"  {name:58s} {e32:9.2e} {eg:9.2e} {er:9.2e}  {verdict}")
 

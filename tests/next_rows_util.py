@@ -94,11 +94,15 @@ def run(device, tol, grad_tol, point_tol, exact_edges=True, adjudicate=False):
     if not (exact_edges or np.array_equal(lit, lit_ref)):
         return
     assert abs(pl.light.grad.item() - float(d["g_light"])) < 2 * tol * abs(float(d["g_light"]))
+    # with `adjudicate` the element-wise verdicts below (fp64 run + the reference's own fp32 spread) are the test; the
+    # max-normalised bounds here then only catch gross errors: which side of a ReLU / relu(-cos) kink a grazing edge
+    # point takes moves a gradient tensor by several 1e-4 between two fp32 evaluation orders, the reference's included
+    grad_tol = grad_tol * (10 if adjudicate else 1)
     assert rel_err(npy(pl.light_offset.weight.grad), d["g_offset"]) < grad_tol
     for k, p in net.named_parameters():
         ref = d[f"g.sdf.{k}"]
         g = npy(p.grad)
-        assert rel_err(g if g.shape == ref.shape else g[::8], ref) < grad_tol, k
+        assert rel_err(g if g.shape == ref.shape else g[::8], ref) < grad_tol, (k, rel_err(g if g.shape == ref.shape else g[::8], ref))
     for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network", "blend_network"):
         for k, p in mats[nm].named_parameters():
             ref = d[f"g.{nm}.{k}"]

@@ -67,8 +67,12 @@ def _shade_on_fixture_points(d, net, mats, dino):
 def test_shading_on_reference_hit_points_within_1e4():
     """get_all + reparam_points + render_fn (full-size material MLPs) + GGX + light_visibility(128) on 2048 hit points
     of the reference's 800 x 800 trace: every output and every parameter gradient element-wise within 1e-4 of the fp32
-    reference, or no farther from the reference's fp64 run than 2 x the fp32 reference itself is."""
+    reference, or no farther from the reference's fp64 run than 2 x the fp32 reference itself is -- "itself" being the
+    worst of its fp32 runs under 8, 6, 4, 3 and 2 CPU threads (shade_points_noise.npz): hit point 2011 of the fixture has
+    a material-network ReLU on its kink, the reference's 2-thread run and any HIP build whose normals round differently
+    in the last bit take the other branch, and every SDF gradient then sits 1e-4 .. 3e-4 from fp64 instead of 1e-5."""
     d = load_golden("shade_points.npz")
+    nz = {k: float(v) for k, v in load_golden("shade_points_noise.npz").items() if k.startswith("noise.")}
     net = sdf_net("sdf_full_bumpy_weights.npz")
     mats, dino = full_materials("cuda")
     results, vis, loss = _shade_on_fixture_points(d, net, mats, dino)
@@ -78,22 +82,22 @@ def test_shading_on_reference_hit_points_within_1e4():
             "diffuse_albedo": results["diffuse_albedo"], "specular_albedo": results["specular_albedo"],
             "specular_roughness": results["specular_roughness"]}
     for k, v in outs.items():
-        ok &= judge(k, np_(v), d[f"ref32.{k}"], d[f"ref64.{k}"], report)
-    ok &= judge("loss", loss.item(), d["ref32.loss"], d["ref64.loss"], report)
+        ok &= judge(k, np_(v), d[f"ref32.{k}"], d[f"ref64.{k}"], report, noise=nz.get(f"noise.{k}"))
+    ok &= judge("loss", loss.item(), d["ref32.loss"], d["ref64.loss"], report, noise=nz.get("noise.loss"))
     pl = mats["point_light_network"]
-    ok &= judge("g_light", np_(pl.light.grad), d["ref32.g_light"], d["ref64.g_light"], report)
-    ok &= judge("g_offset", np_(pl.light_offset.weight.grad), d["ref32.g_offset"], d["ref64.g_offset"], report)
+    ok &= judge("g_light", np_(pl.light.grad), d["ref32.g_light"], d["ref64.g_light"], report, noise=nz.get("noise.g_light"))
+    ok &= judge("g_offset", np_(pl.light_offset.weight.grad), d["ref32.g_offset"], d["ref64.g_offset"], report, noise=nz.get("noise.g_offset"))
 
     def sub(g, ref):
         return g if g.shape == ref.shape else g[::8]
     for k, p in net.named_parameters():
         ref = d[f"ref32.g.sdf.{k}"]
-        ok &= judge(f"g.sdf.{k}", sub(np_(p.grad), ref), ref, d[f"ref64.g.sdf.{k}"], report)
+        ok &= judge(f"g.sdf.{k}", sub(np_(p.grad), ref), ref, d[f"ref64.g.sdf.{k}"], report, noise=nz.get(f"noise.g.sdf.{k}"))
     for nm in ("diffuse_albedo_network", "specular_albedo_network", "specular_roughness_network"):
         for k, p in mats[nm].named_parameters():
             ref = d[f"ref32.g.{nm}.{k}"]
             g = np_(p.grad) if p.grad is not None else np.zeros(p.shape, np.float32)
-            ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report)
+            ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report, noise=nz.get(f"noise.g.{nm}.{k}"))
     ok = verdicts(report)
     print_report(report, "shading on the reference's hit points (HIP)")
     n_direct = sum(1 for r in report if r[4] == "ok")

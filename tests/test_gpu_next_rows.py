@@ -67,8 +67,8 @@ def test_training_step_matches_reference():
 
 
 def test_training_step_adjudicated_with_the_reference_hit_points():
-    """The same iteration with the PRIMARY hit points pinned to the fp32 reference's (so that no primary ray stops an
-    iteration apart): every tensor -- colour, the eight loss terms, every parameter gradient of the five networks
+    """The same iteration with the hit points of EVERY tracer call pinned to the fp32 reference's (primary rays, the
+    secondary rays of the indirect bounce, the edge-pixel rays: no ray stops an iteration apart): every tensor -- colour, the eight loss terms, every parameter gradient of the five networks
     and the light -- is judged element-wise against the fp32 reference with its fp64 run as the arbiter."""
     import train_step_util
     out = train_step_util.run("cuda", tol=1e-4, grad_tol=1.5e-3, exact=False, mat_grad_tol=1e-2, adjudicate=True,

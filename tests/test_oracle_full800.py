@@ -34,6 +34,7 @@ def test_oracle_trace_subsample_of_800_view():
 
 def test_oracle_shading_on_reference_hit_points():
     d = load_golden("shade_points.npz")
+    nz = {k: float(v) for k, v in load_golden("shade_points_noise.npz").items() if k.startswith("noise.")}
     t = load_golden("trace_full800.npz")
     sdf_state = {k: v.clone().requires_grad_(True) for k, v in state_from_npz(load_golden("sdf_full_bumpy_weights.npz")).items()}
     mats, dino = full_materials("cpu")
@@ -63,18 +64,18 @@ def test_oracle_shading_on_reference_hit_points():
     report, ok = [], True
     for k, v in (("vis", vis), ("color", out["color"]), ("normal", out["normal"]),
                  ("diffuse_albedo", out["diffuse_albedo"]), ("specular_roughness", out["specular_roughness"])):
-        ok &= judge(k, v.detach().numpy(), d[f"ref32.{k}"], d[f"ref64.{k}"], report)
-    ok &= judge("g_light", light.grad.numpy(), d["ref32.g_light"], d["ref64.g_light"], report)
-    ok &= judge("g_offset", off.grad.numpy(), d["ref32.g_offset"], d["ref64.g_offset"], report)
+        ok &= judge(k, v.detach().numpy(), d[f"ref32.{k}"], d[f"ref64.{k}"], report, noise=nz.get(f"noise.{k}"))
+    ok &= judge("g_light", light.grad.numpy(), d["ref32.g_light"], d["ref64.g_light"], report, noise=nz.get("noise.g_light"))
+    ok &= judge("g_offset", off.grad.numpy(), d["ref32.g_offset"], d["ref64.g_offset"], report, noise=nz.get("noise.g_offset"))
     sub = lambda g, ref: g if g.shape == ref.shape else g[::8]  # noqa: E731
     for k, v in sdf_state.items():
         ref = d[f"ref32.g.sdf.{k}"]
-        ok &= judge(f"g.sdf.{k}", sub(v.grad.numpy(), ref), ref, d[f"ref64.g.sdf.{k}"], report)
+        ok &= judge(f"g.sdf.{k}", sub(v.grad.numpy(), ref), ref, d[f"ref64.g.sdf.{k}"], report, noise=nz.get(f"noise.g.sdf.{k}"))
     for nm, st in mstates.items():
         for k, v in st.items():
             ref = d[f"ref32.g.{nm}.{k}"]
             g = v.grad.numpy() if v.grad is not None else np.zeros(v.shape, np.float32)
-            ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report)
+            ok &= judge(f"g.{nm}.{k}", sub(g, ref), ref, d[f"ref64.g.{nm}.{k}"], report, noise=nz.get(f"noise.g.{nm}.{k}"))
     ok = verdicts(report)
     print_report(report, "shading on the reference's hit points (oracle, CPU fp32)")
     assert ok, [r for r in report if r[4] == "FAIL"]

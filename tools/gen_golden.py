@@ -522,7 +522,23 @@ def main():
         ts.update(state_to_np("mat.blend_network.", t_cnd["blend_network"]))
         np.random.seed(71)
         torch.manual_seed(72)
-        exec("\n".join(lines[544:699]), ns3)
+        # every tracer call of the step, in order (primary rays, secondary rays of the indirect bounce, the two sides of
+        # the edge pixels): lets the adjudicated GPU test pin ALL stop decisions of the sphere tracer, not only the
+        # primary ones (a secondary ray starts on the surface along a reflected direction; its hit point moves by 1e-4
+        # when the normal it was reflected about changes in the last bit)
+        trace_calls = []
+        real_forward = tracer.forward
+
+        def recording_forward(*a, **k):
+            out_ = real_forward(*a, **k)
+            trace_calls.append({"ray_o": _np(a[1]), "ray_d": _np(a[2]), "mask": _np(out_["convergent_mask"]),
+                                "points": _np(out_["points"]), "distance": _np(out_["distance"]), "sdf": _np(out_["sdf"])})
+            return out_
+        tracer.forward = recording_forward
+        try:
+            exec("\n".join(lines[544:699]), ns3)
+        finally:
+            del tracer.forward
         torch.manual_seed(72)
         ts["eik_points"] = _np(torch.empty(32 * 32 // 2, 3).float().uniform_(-1.0, 1.0))
         for k in ("loss", "img_loss", "img_l1_loss", "img_l2_loss", "img_ssim_loss", "eik_loss", "roughrange_loss",
@@ -548,7 +564,17 @@ def main():
         ts["after.diffuse.lin0.bias"] = _np(t_cnd["diffuse_albedo_network"].lin0.bias)
         print("train step: loss", ts["out.loss"], "hits", int(ts["out.mask"].sum()), "edges", int(ts["out.edge_mask"].sum()),
               "smooth", ts["out.smoothness_loss"], "rough", ts["out.roughrange_loss"], "idx", ts["out.idx"])
+        tc = {"n_calls": np.int64(len(trace_calls))}
+        for i, c in enumerate(trace_calls):
+            tc.update({f"call{i}.{k}": v for k, v in c.items()})
+        print("train step: tracer calls with", [int(c["mask"].size) for c in trace_calls], "rays")
+        prev_path = os.path.join(out_dir, "train_step.npz")
+        if os.path.exists(prev_path):
+            prev = np.load(prev_path)
+            changed = [k for k in ts if k in prev.files and not np.array_equal(np.asarray(ts[k]), prev[k])]
+            print("train step: keys that differ from the fixture on disk:", changed[:10], len(changed))
         save(os.path.join(out_dir, "train_step.npz"), **ts)
+        save(os.path.join(out_dir, "train_step_traces.npz"), **tc)
 
     # K = 5 consecutive iterations of the same loop text (round 3): Adam state, the optimizer
     # schedule across a phase change, weight re-packing after every step.  global_step 11998..12002 with

@@ -326,6 +326,9 @@ def main():
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default="e2e,nx,ts")
     ap.add_argument("--noise-threads", default="1,2,3,4,6,8", help="thread counts of the fp32 re-runs of the reference")
+    ap.add_argument("--noise-rows", default="0", help="rows per GEMM slice of the fp32 re-runs (0 = whole batches)")
+    ap.add_argument("--noise-gemm", default="", help="other summation orders of nn.Linear: flipk,split2,exact")
+    ap.add_argument("--keep-noise", action="store_true", help="extend the noise floor stored in the file")
     args = ap.parse_args()
     only = set(args.only.split(","))
     GG._install_stubs()
@@ -335,10 +338,13 @@ def main():
     if os.path.exists(path):       # partial regeneration keeps the other sections
         old = np.load(path)
         out.update({k: old[k] for k in old.files})
-    for sec in only:
+    for sec in only if not args.keep_noise else ():
         for k in [k for k in out if k.startswith(sec + ".") or k.startswith("noise." + sec + ".")]:
             del out[k]
-    ref64 = run_variant(args, only, torch.float64, 8)
+    if args.keep_noise:
+        ref64 = {k: old[k] for k in old.files if k.split(".")[0] in only}
+    else:
+        ref64 = run_variant(args, only, torch.float64, 8)
     out.update(ref64)
     # Round-off floor of the reference ITSELF: the same fp32 code on the same inputs, re-run with different CPU thread
     # counts (MKL / OpenMP partition the GEMMs and reductions differently, so every run rounds differently; two runs of
@@ -346,14 +352,51 @@ def main():
     # element-wise distance from the fp64 run over those re-runs is stored as noise.<tensor>; only runs whose masks
     # equal the fp64 run's are counted.
     threads = [int(t) for t in args.noise_threads.split(",") if t]
+    slices = [int(r) for r in args.noise_rows.split(",") if r]
     noise, used = {}, []
-    for t in threads:
-        v = run_variant(args, only, torch.float32, t)
+    if args.keep_noise:            # add re-runs to the floor already in the file instead of starting over
+        noise = {k[len("noise."):]: float(old[k]) for k in old.files if k.startswith("noise.") and k[6:].split(".")[0] in only}
+        used = [int(t) for t in old["noise_threads"]] if "noise_threads" in old.files else []
+    real_linear = torch.nn.functional.linear
+    # Other summation orders of every nn.Linear of the reference (the small GEMMs of the 32-wide fixture networks take
+    # the same MKL path whatever the thread count: those re-runs are bit-identical, i.e. ONE sample of the fp32 spread):
+    #   rows > 0   the input evaluated in slices of `rows` rows (another blocking of the GEMM)
+    #   -1 flipk   the K dimension summed in reverse order
+    #   -2 split2  two half-K products added (what a K-split GPU kernel does)
+    #   -3 exact   products accumulated in double and rounded once per output (the best an fp32 layer can be)
+    gemm_modes = {"flipk": -1, "split2": -2, "exact": -3}
+    slices += [gemm_modes[m] for m in args.noise_gemm.split(",") if m]
+    for t, rows in [(t, r) for r in slices for t in (threads if r >= 0 else threads[-1:])]:
+        if rows > 0:
+            def sliced(x, w, b=None, _r=rows):
+                if x.dim() == 2 and x.shape[0] > _r:
+                    return torch.cat([real_linear(c, w, b) for c in x.split(_r)], 0)
+                return real_linear(x, w, b)
+            torch.nn.functional.linear = sliced
+        elif rows == -1:
+            torch.nn.functional.linear = lambda x, w, b=None: real_linear(x.flip(-1), w.flip(-1), b)
+        elif rows == -2:
+            def split2(x, w, b=None):
+                h = x.shape[-1] // 2
+                y = real_linear(x[..., :h], w[:, :h]) + real_linear(x[..., h:], w[:, h:])
+                return y if b is None else y + b
+            torch.nn.functional.linear = split2
+        elif rows == -3:
+            def exact(x, w, b=None):
+                if x.dtype != torch.float32:
+                    return real_linear(x, w, b)
+                y = real_linear(x.double(), w.double(), None if b is None else b.double())
+                return y.float()
+            torch.nn.functional.linear = exact
+        try:
+            v = run_variant(args, only, torch.float32, t)
+        finally:
+            torch.nn.functional.linear = real_linear
         same = all(np.array_equal(v[k], ref64[k]) for k in ref64 if ref64[k].dtype == np.bool_)
-        print(f"fp32 re-run on {t} threads: masks equal to the fp64 run: {same}", flush=True)
+        print(f"fp32 re-run on {t} threads, GEMM mode {rows}: masks equal to the fp64 run: {same}", flush=True)
         if not same:
             continue
-        used.append(t)
+        used.append(t if not rows else 1000 * rows + (t if rows > 0 else -t))
         for k, a in ref64.items():
             if a.dtype.kind == "f":
                 noise[k] = max(noise.get(k, 0.0), elem_err(v[k], a))

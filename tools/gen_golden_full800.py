@@ -81,7 +81,7 @@ def main():
                             sub_ray_d_norm=r["ray_d_norm"].reshape(-1).numpy()[sub],
                             ray_o=r["ray_o"].reshape(-1, 3).numpy()[0])
 
-    if args.only in ("", "shade"):
+    if args.only in ("", "shade", "noise"):
         tr = np.load(trace_path)
         mask = np.unpackbits(tr["mask_bits"])[:res * res].astype(bool)
         sub = tr["sub_idx"]
@@ -100,7 +100,30 @@ def main():
                    pixel_idx=sub[pick], light_offset=np.array([[0.2, 0.1, 0.0]], np.float32),
                    inv_s=np.float32(np.exp(3.0)))
 
-        for tag, dtype in (("ref32", torch.float32), ("ref64", torch.float64)):
+        # "noise": the fp32 reference re-run under other CPU thread counts (another GEMM blocking = another fp32
+        # rounding of the same code); per tensor, the largest element-wise distance of those runs from the fp64 run
+        # goes to shade_points_noise.npz -- the reference's own fp32 spread on this fixture (ReLU / clamp kinks of the
+        # material networks flip under round-off of the normals that feed them), the yardstick of the GPU test
+        runs = [("ref32", torch.float32, 8), ("ref64", torch.float64, 8)] if args.only != "noise" else \
+            [(f"alt{t}", torch.float32, t) for t in (6, 4, 3, 2)] + [("flipk", torch.float32, 8), ("split2", torch.float32, 8),
+                                                                    ("exact", torch.float32, 8)]
+        real_linear = F.linear
+
+        def flipk(x, w, b=None):            # K summed in reverse order
+            return real_linear(x.flip(-1), w.flip(-1), b)
+
+        def split2(x, w, b=None):           # two half-K products added
+            h = x.shape[-1] // 2
+            y = real_linear(x[..., :h], w[:, :h]) + real_linear(x[..., h:], w[:, h:])
+            return y if b is None else y + b
+
+        def exact(x, w, b=None):            # accumulated in double, rounded once per output
+            if x.dtype != torch.float32:
+                return real_linear(x, w, b)
+            return real_linear(x.double(), w.double(), None if b is None else b.double()).float()
+        for tag, dtype, threads in runs:
+            torch.nn.functional.linear = {"flipk": flipk, "split2": split2, "exact": exact}.get(tag, real_linear)
+            torch.set_num_threads(threads)
             torch.set_default_dtype(dtype)
             src = text if dtype == torch.float32 else text.replace("dtype=torch.float32", "dtype=torch.float64")
             ns = dict(torch=torch, nn=nn, F=F, np=np, dino_dimension=384,
@@ -155,6 +178,27 @@ def main():
             for nm in MAT:
                 out.update({f"{tag}.g.{nm}." + k: v for k, v in sub_grads(cnd[nm].named_parameters()).items()})
         torch.set_default_dtype(torch.float32)
+        torch.set_num_threads(8)
+        torch.nn.functional.linear = real_linear
+        if args.only == "noise":
+            sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+            from full800_util import elem_err
+            fx = np.load(os.path.join(GOLDEN, "shade_points.npz"))
+            noise = {}
+            for k in fx.files:
+                if not k.startswith("ref64."):
+                    continue
+                name = k[len("ref64."):]
+                floor = np.abs(fx[k].astype(np.float64)).mean() + 1e-300
+                errs = [elem_err(out[f"{tag}.{name}"], fx[k], floor) for tag, _, _ in runs]
+                noise["noise." + name] = np.float64(max(errs))
+                own = elem_err(fx["ref32." + name], fx[k], floor)
+                if max(errs) > 2 * own and max(errs) > 1e-5:
+                    print(f"  {name}: fp32 reference vs fp64 {own:.2e}, other thread counts {[f'{e:.2e}' for e in errs]}")
+            noise["noise_runs"] = np.asarray([{"flipk": -1, "split2": -2, "exact": -3}.get(tag, t) for tag, _, t in runs])   # thread count, or the summation-order code
+            np.savez_compressed(os.path.join(GOLDEN, "shade_points_noise.npz"), **noise)
+            print("wrote shade_points_noise.npz", flush=True)
+            return
         np.savez_compressed(os.path.join(GOLDEN, "shade_points.npz"), **out)
         print("wrote shade_points.npz", flush=True)
 
