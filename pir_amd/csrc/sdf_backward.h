@@ -17,14 +17,15 @@ namespace pir {
 #endif
 #endif
 
-// Cache policy of the sweep's scratch traffic (each 1: on; A/B builds pass -D...=0).  The 2 x 2.1 MB of packed weights
-// every tile re-reads share the 4 MB L2 of an XCD with 55 KB per point of scratch traffic streaming through it:
-//   PIR_BWD_NT_QZ   Q / Zb (written here, read by a later launch) are stored non-temporally
-//   PIR_BWD_NT_LD   the A / Ad fragments the GZ epilogues read back (once) are loaded non-temporally
-//   PIR_BWD_TOUCH   one dword per 128-byte line of the NEXT layer's A / Ad fragments is loaded before each GZ product,
-//                   so that the epilogue's loads find their lines on the way instead of starting an HBM round trip
-// Measured on 2 M points (profiles/r03_bwd_cache_policy_ab.log): 68.8 -> 67.0 ms for the three together; storing A / Ad
-// non-temporally as well costs 1.3 % (they are re-read within the tile), and neither policy helps get_all's spill ring.
+// Cache policy of the sweep's scratch traffic (A/B builds pass -D...=0 / =1).  The 2 x 2.1 MB of packed weights every
+// tile re-reads share the 4 MB L2 of an XCD with 55 KB per point of scratch traffic streaming through it:
+//   PIR_BWD_NT_QZ (on)   Q / Zb (written here, read by a later launch) are stored non-temporally
+//   PIR_BWD_NT_LD (on)   the A / Ad fragments the GZ epilogues read back (once) are loaded non-temporally
+//   PIR_BWD_TOUCH (off)  one dword per 128-byte line of the NEXT layer's A / Ad fragments loaded before each GZ product
+// Measured on 2 M points (profiles/r03_bwd_cache_policy_ab.log): 68.8 -> 67.0 ms for the first two.  The touch-ahead
+// is worth 1.1 % on its own but nothing on top of them (65.25 vs 65.05 ms) and re-fetches half of the lines it touches
+// (PMC: +9 KB / point of HBM reads); storing A / Ad non-temporally as well costs 1.3 % (they are re-read within the
+// tile); neither policy helps get_all's spill ring.
 #ifndef PIR_BWD_NT_QZ
 #define PIR_BWD_NT_QZ 1
 #endif
@@ -32,7 +33,7 @@ namespace pir {
 #define PIR_BWD_NT_LD 1
 #endif
 #ifndef PIR_BWD_TOUCH
-#define PIR_BWD_TOUCH (PIR_BWD_FRAG)
+#define PIR_BWD_TOUCH 0
 #endif
 
 // HBM scratch of one chunk of points, every array [chunk_rows][256] fp32 (layout above)
