@@ -211,3 +211,15 @@ def test_embed_kernels_match_the_eager_encoding_to_second_order(D, L):
     assert L_.pir_embed_forward(0, D, L, None, None, None) == 0
     assert L_.pir_embed_forward(4, 0, L, _lib.ptr(x0), _lib.ptr(o1), None) == 1
     assert L_.pir_embed_backward(4, D, 17, _lib.ptr(x0), _lib.ptr(c0), _lib.ptr(w), None) == 1
+
+
+def test_abi_error_conventions_zero_sizes_and_null_pointers():
+    """SURVEY 8(b), error conventions of the C ABI on the GPU box: sizes of 0 are accepted and do nothing, a negative
+    size or a missing required pointer is PIR_ERR_ARG, returned BEFORE anything is launched (tests/abi_util.py; the same
+    cases run without a GPU in tests/test_host_logic.py)."""
+    import abi_util
+    from pir_amd import _lib
+    buf = torch.zeros(4096, device="cuda")
+    abi_util.check_error_conventions(_lib.lib(), buf.data_ptr(), _lib.stream_ptr())
+    torch.cuda.synchronize()
+    assert float(buf.abs().sum()) == 0.0                                  # nothing was written

@@ -380,6 +380,17 @@ def test_product_code_never_touches_the_oracle_or_the_reference():
         assert ref not in text, f
 
 
+def test_abi_error_conventions_without_a_gpu():
+    """Argument validation of the C ABI happens before any HIP call: zero sizes, negative sizes, null pointers and
+    out-of-range parameters return their status codes on a machine without a GPU as well (no kernel is launched)."""
+    import ctypes
+    import abi_util
+    from pir_amd import _lib
+    host = (ctypes.c_float * 4096)()
+    abi_util.check_error_conventions(_lib.lib(), ctypes.addressof(host), None)
+    assert not any(host)
+
+
 def test_kernels_fail_loudly_without_the_library(monkeypatch):
     from pir_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
