@@ -61,11 +61,16 @@ __device__ __forceinline__ float smith_g1(float c, float a) {
 // from (a <= 1 ulp vectorised pow, in practice the correctly rounded value).  powf is within 2 ulp of that, which can
 // only move the result when w * scale sits within ~2.4e-5 of an integer; those points (about 2 in 1000) take the
 // exact path: x ** 0.25 correctly rounded through double (two correctly rounded square roots, one rounding to float).
+// The fast path only has to be within 1e-3 / scale of the true value: sqrtf(sqrtf(x)) is (<= 1 ulp).
 __device__ __forceinline__ long quarter_bin(float x, float scale) {
 #ifdef PIR_GGX_POWF      // A/B: the round-2 form (bare powf: 0.2 % of the bins one off)
   return (long)floorf(powf(x, 0.25f) * scale);
 #else
+#ifdef PIR_GGX_POWF_FAST     // A/B: powf on the fast path (round 3 until the last day: ~100 instructions per call)
   float t = powf(x, 0.25f) * scale;
+#else
+  float t = sqrtf(sqrtf(x)) * scale;     // two correctly rounded roots: within 1 ulp of x ** 0.25, a tenth of powf's cost
+#endif
   float fl = floorf(t);
   if (t - fl < 1e-3f || fl + 1.0f - t < 1e-3f) {
     t = (float)sqrt(sqrt((double)x)) * scale;
@@ -207,8 +212,11 @@ ggx_forward_v4_kernel(long P, const float* __restrict__ light, int light_rgb, in
       const float nn[3] = {n.f[3 * j], n.f[3 * j + 1], n.f[3 * j + 2]};
       const float ll[3] = {l.f[3 * j], l.f[3 * j + 1], l.f[3 * j + 2]};
       const float vv[3] = {v.f[3 * j], v.f[3 * j + 1], v.f[3 * j + 2]};
+      // by value: selecting between the addresses of two register arrays would put both into scratch memory
+      const float lrgb[3] = {light_rgb ? lt.f[3 * j] : light0, light_rgb ? lt.f[3 * j + 1] : light0,
+                             light_rgb ? lt.f[3 * j + 2] : light0};
       GgxPoint p;
-      ggx_eval(p, light_rgb ? &lt.f[3 * j] : &light0, light_rgb, edr, d4.f[j], nn, ll, vv, al4.f[j], tb);
+      ggx_eval(p, lrgb, 1, edr, d4.f[j], nn, ll, vv, al4.f[j], tb);
       ggx_point_out(p, &a_kd.f[3 * j], &a_ks.f[3 * j], &od.f[3 * j], &os.f[3 * j], &orgb.f[3 * j]);
     }
 #pragma unroll
