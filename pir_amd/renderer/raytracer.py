@@ -439,12 +439,18 @@ def _fill_holes(results):
                                     results["points"])
 
 
+_SOBEL = {}
+
+
 def _sobel_magnitude(depth):
     """kornia.filters.sobel without kornia: 3x3 Sobel kernels normalised by 8, replicate padding,
     sqrt(gx^2 + gy^2 + 1e-6) (kornia's published algorithm; parity with kornia itself unpinned)."""
-    kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]], device=depth.device) / 8.0
+    w = _SOBEL.get(depth.device)
+    if w is None:      # built once per device: a host-to-device copy per call waits for everything queued on the stream
+        kx = torch.tensor([[-1.0, 0.0, 1.0], [-2.0, 0.0, 2.0], [-1.0, 0.0, 1.0]]) / 8.0
+        w = _SOBEL[depth.device] = torch.stack([kx, kx.t()])[:, None].to(depth.device)
     x = F.pad(depth[None, None], (1, 1, 1, 1), mode="replicate")
-    g = F.conv2d(x, torch.stack([kx, kx.t()])[:, None])[0]
+    g = F.conv2d(x, w)[0]
     return torch.sqrt(g[0] * g[0] + g[1] * g[1] + 1e-6)
 
 

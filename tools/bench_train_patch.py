@@ -90,7 +90,8 @@ def main():
     state = build_state(dev, args.patch, args.stage, handle_edges=not args.no_edges)
     from pir_amd import train
     from pir_amd.renderer.raytracer import Camera
-    corners = object_crops(800, args.patch, args.warmup + args.steps, seed=3)
+    # the timed steps always see the same crops and views, whatever the warm-up length (warm-up cycles through them too)
+    corners = object_crops(800, args.patch, args.steps, seed=3)
     it = {"i": 0}
     orig_crop = Camera.crop_region
 
@@ -107,12 +108,14 @@ def main():
         it["i"] = i
         train.training_step(state, args.global_step)
     sync()
+    np.random.seed(4)
+    torch.manual_seed(5)
     if dev.type == "cuda":
         torch.erfinv(marker)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        it["i"] = args.warmup + i
+        it["i"] = i
         out = train.training_step(state, args.global_step)
         if dev.type == "cpu":
             print(f"[train_patch] cpu step {i + 1}/{args.steps} ({time.perf_counter() - t0:.0f} s)", file=sys.stderr,
