@@ -79,7 +79,12 @@ def test_ggx_matches_reference(tag, edr):
         ref = d[f"{tag}.{k}"]
         got = o[k].detach().cpu().numpy()
         bad = np.abs(got - ref) > 1e-4 * np.abs(ref) + 1e-4 * np.abs(ref).mean()
-        assert bad.mean() < 1e-3, (tag, k, bad.sum())   # floor()-indexed tables may flip a bin on a handful of points
+        worst = np.abs(got - ref)[bad].max() / np.abs(ref).mean() if bad.any() else 0.0
+        print(f"ggx {tag} {k}: {int(bad.sum())} of {bad.size} elements outside 1e-4 (worst {worst:.1e} of the mean)")
+        # the table bins are the reference's, point for point: no allowance for the diffuse term.  The specular term of the
+        # fixture's alpha = 1e-4 edge cases has a condition number of 1 / alpha^2 = 1e8 in cos_h (D's denominator): one
+        # such point (2 channels) lands 1e-3 away in the collocated case
+        assert bad.sum() <= (0 if k == "diffuse_rgb" else 3), (tag, k, bad.sum())
     (o["rgb"] * torch.from_numpy(d[f"{tag}.cw"]).cuda()).sum().backward()
     assert abs(light.grad.item() - float(d[f"{tag}.g_light"])) < 2e-4 * abs(float(d[f"{tag}.g_light"]))
     for n in names:
@@ -88,6 +93,7 @@ def test_ggx_matches_reference(tag, edr):
         ref = d[f"{tag}.g_{n}"]
         got = leaves[n].grad.cpu().numpy()
         bad = np.abs(got - ref) > 2e-4 * np.abs(ref) + 1e-4 * np.abs(ref).mean() + 1e-12
+        print(f"ggx {tag} d/d{n}: {int(bad.sum())} of {bad.size} elements outside 2e-4")
         assert bad.mean() < 2e-3, (tag, n, bad.sum())
 
 
@@ -100,7 +106,7 @@ def test_ggx_rgb_light_and_known_answers():
             EDirectRadiance=False)
     ref = d["rgblight.rgb"]
     bad = np.abs(o["rgb"].cpu().numpy() - ref) > 1e-4 * np.abs(ref) + 1e-4 * np.abs(ref).mean()
-    assert bad.mean() < 1e-3
+    assert not bad.any(), bad.sum()
     one = lambda *v: torch.tensor([list(v)], dtype=torch.float32, device="cuda")  # noqa
     nrm = one(0, 0, 1)
     o = ggx(torch.tensor(10.0), one(2.0), nrm, nrm, nrm, one(.5, .5, .5), one(.5, .5, .5), one(0.1))
@@ -371,3 +377,55 @@ def test_sampler_first_negative_index_equals_the_reference_min_idx(name, iters):
           f"first-negative index equal on {int(common.sum()) - differ.size} of {int(common.sum())} common rays"
           + (f"; disputed samples have |sdf| <= {worst:.1e}" if differ.size and iters == 0 else "")
           + (f"; the reference differs from itself on {own} rays when its fp32 evaluation order changes" if iters else ""))
+
+
+def test_ggx_properties_at_four_million_points():
+    """Size-independent properties of the shader at 4 M + 3 points (register kernel + scalar tail): exact homogeneity
+    (light x 2 doubles every output bit for bit; kd x 0.5 halves the diffuse term and leaves the specular term
+    untouched), the same values from unaligned buffers (LDS-staged kernel) as from aligned ones (register kernel), the
+    tail points equal to the same points evaluated alone, and rgb = diffuse + specular exactly."""
+    from pir_amd.renderer.renderer_ggx import GGXColocatedRenderer
+    ggx = GGXColocatedRenderer(use_cuda=True)
+    P = (1 << 22) + 3
+    g = torch.Generator(device="cuda").manual_seed(9)
+    unit = lambda t: torch.nn.functional.normalize(t, dim=-1)  # noqa: E731
+    n = unit(torch.randn(P, 3, device="cuda", generator=g))
+    l = unit(n + 0.7 * torch.randn(P, 3, device="cuda", generator=g))
+    v = unit(n + 0.7 * torch.randn(P, 3, device="cuda", generator=g))
+    dist = 2.0 + torch.rand(P, 1, device="cuda", generator=g)
+    kd, ks = torch.rand(P, 3, device="cuda", generator=g), torch.rand(P, 3, device="cuda", generator=g)
+    alpha = 0.01 + 0.6 * torch.rand(P, 1, device="cuda", generator=g)
+    light = torch.tensor(135.0, device="cuda")
+    with torch.no_grad():
+        o = ggx(light, dist, n, l, v, kd, ks, alpha)
+        o2 = ggx(light * 2, dist, n, l, v, kd, ks, alpha)
+        o3 = ggx(light, dist, n, l, v, kd * 0.5, ks, alpha)
+        assert all(torch.equal(o2[k], 2 * o[k]) for k in o)
+        assert torch.equal(o3["diffuse_rgb"], 0.5 * o["diffuse_rgb"]) and torch.equal(o3["specular_rgb"], o["specular_rgb"])
+        assert rel_err(o["rgb"].cpu(), (o["diffuse_rgb"] + o["specular_rgb"]).cpu()) < 2e-7       # one rounding (the sum may be fused)
+        assert torch.isfinite(o["rgb"]).all() and (o["diffuse_rgb"] >= 0).all() and (o["specular_rgb"] >= 0).all()
+
+        def shifted(t):      # the same values at an address that is NOT 16-byte aligned
+            flat = torch.empty(t.numel() + 1, device="cuda")
+            flat[1:] = t.reshape(-1)
+            return flat[1:].view(t.shape)
+        # straight through the C ABI (the Python mirror would copy an unaligned tensor to an aligned one)
+        from pir_amd import _lib
+        t_rough, t_diff = ggx._tables_on(n.device)
+        ns = shifted(n)
+        assert ns.data_ptr() % 16 != 0
+        outs = [torch.empty(P, 3, device="cuda") for _ in range(3)]
+        args = [dist.reshape(P), ns, l, v, kd, ks, alpha.reshape(P)]
+        assert _lib.lib().pir_ggx_forward(P, _lib.ptr(light.reshape(1)), 0, 1, *[_lib.ptr(a) for a in args],
+                                          _lib.ptr(t_rough), t_rough.numel(), _lib.ptr(t_diff), t_diff.numel(),
+                                          *[_lib.ptr(t) for t in outs], _lib.stream_ptr()) == 0
+        for k, got in zip(("diffuse_rgb", "specular_rgb", "rgb"), outs):
+            # two kernels, same source arithmetic: the compiler contracts the cosines differently (1 ulp), which moves the
+            # few points that sit within an ulp of a table-bin edge into the neighbouring bin (a 1e-3 step of the diffuse term)
+            off = ((got - o[k]).abs() > 1e-6 * o[k].abs().max()).sum().item()
+            print(f"ggx unaligned-buffer kernel vs register kernel, {k}: {off} of {got.numel()} elements differ by > 1e-6")
+            assert off < 1e-4 * got.numel(), (k, off)
+            assert rel_err(got.cpu(), o[k].cpu()) < 1e-3, k
+        tail = slice(P - 3, P)
+        ot = ggx(light, dist[tail], n[tail], l[tail], v[tail], kd[tail], ks[tail], alpha[tail])
+        assert all(torch.equal(ot[k], o[k][tail]) for k in o)
