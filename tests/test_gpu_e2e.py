@@ -154,7 +154,9 @@ def test_ggx_million_points_vs_torch_formula():
     out = ggx(light, *leaves)
     ref = ggx._forward_torch(light, *leaves_ref, True)
     bad = (out["rgb"] - ref["rgb"]).abs() > 1e-4 * ref["rgb"].abs() + 1e-5 * ref["rgb"].abs().mean()
-    assert bad.float().mean().item() < 1e-4       # floor()-indexed tables: a bin may flip on isolated points
+    # the comparison partner here is torch's GPU expression, whose pow is not the reference's CPU pow: its bins differ from
+    # the reference's (and hence from the kernel's) on isolated points; bins vs the reference itself: test_gpu_render.py
+    assert bad.float().mean().item() < 1e-4
     w = torch.rand(P, 3, generator=g).cuda()
     (out["rgb"] * w).sum().backward()
     (ref["rgb"] * w).sum().backward()
