@@ -24,6 +24,7 @@ __device__ constexpr Prod kRev[9] = {kR0P, kR1, kR2, kR3, kR4, kR5, kR6, kR7, kR
 // the last wave) is all padding: its MFMAs are not issued and its accumulators stay 0, which is what the zero weight
 // rows produced (round 1 executed them).  The matrix pipe is shared with the co-resident workgroup, so the saving
 // shows although the other waves of this workgroup still run two tiles.
+template <bool ONLY1 = false>
 __device__ __forceinline__ void fwd_gemm_phase(const SdfPacked& pk, int ph, const Lds& lds, f32x16 (&acc)[kSets][kTPW],
                                                f32x4 (&pre)[kTPW], bool prefetch_next, Prod next) {
   const int w = wave_id();
@@ -32,13 +33,13 @@ __device__ __forceinline__ void fwd_gemm_phase(const SdfPacked& pk, int ph, cons
     f32x4 p1[1] = {pre[0]};
 #pragma unroll
     for (int s = 0; s < kSets; ++s) a1[s][0] = acc[s][0];
-    gemm_phase_pre<1, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), a1, p1, prefetch_next, next);
+    gemm_phase_pre<1, ONLY1, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), a1, p1, prefetch_next, next);
 #pragma unroll
     for (int s = 0; s < kSets; ++s) acc[s][0] = a1[s][0];
     pre[0] = p1[0];
     if (prefetch_next) pre[kTPW - 1] = pk.mats[next.off + (size_t)(kTPW * w + kTPW - 1) * kTileKB + lane_id()];
   } else {
-    gemm_phase_pre<kTPW, false, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre, prefetch_next, next);
+    gemm_phase_pre<kTPW, ONLY1, true>(pk.mats, kFwdPh[ph], kTPW * w, lds, fwd_phase_kb0(ph), acc, pre, prefetch_next, next);
   }
 }
 
@@ -50,7 +51,9 @@ constexpr int kScratchWgF4 = 8 * kScratchLayerF4;         // a0..a7
 #endif
 constexpr size_t kScratchWgBytes = (size_t)kScratchWgF4 * sizeof(f32x4);
 
-template <bool STORE>
+// ONLY1: only operand set 1 carries points (a 32-point tile for short work lists): the products of set 0 are not
+// issued -- half the matrix work of a pass; its accumulators stay 0 and its epilogues run on bias values.
+template <bool STORE, bool ONLY1 = false>
 __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, float x0, float x1, float x2,
                                                f32x4* __restrict__ scratch) {
   const int w = wave_id();
@@ -62,7 +65,7 @@ __device__ __forceinline__ void forward_hidden(Lds& lds, const SdfPacked& pk, fl
 #pragma nounroll
   for (int ph = 0; ph < kFwdPhases; ++ph) {
     if (fwd_phase_first(ph)) zero_acc(acc);
-    fwd_gemm_phase(pk, ph, lds, acc, pre, ph < kFwdPhases - 1, kFwdPh[ph < kFwdPhases - 1 ? ph + 1 : ph]);
+    fwd_gemm_phase<ONLY1>(pk, ph, lds, acc, pre, ph < kFwdPhases - 1, kFwdPh[ph < kFwdPhases - 1 ? ph + 1 : ph]);
     PIR_STAMP(1);
     if (!fwd_phase_last(ph)) continue;
     const int l = fwd_phase_layer(ph);

@@ -42,6 +42,20 @@ __device__ __forceinline__ void eval_tile(Lds& lds, const SdfPacked& pk, float x
   __syncthreads();
 }
 
+// Short work lists (a 64 x 64 training patch is 4 096 rays = 64 tiles of 64 points for 256 CUs): when one 32-entry tile
+// per workgroup covers the list, a workgroup takes 32 entries in operand set 1 only -- twice as many CUs busy, half the
+// matrix work per pass.  Entry e of the tile is supplied by lane (wave 1, j = e) and read back as (set 1, e).
+#ifndef PIR_TRACE_HALF
+#define PIR_TRACE_HALF 1       // 0: A/B build without the short-list mode
+#endif
+constexpr int kHalfPts = 32;
+__device__ __forceinline__ bool half_tiles(int count) { return PIR_TRACE_HALF && count <= (int)gridDim.x * kHalfPts; }
+__device__ __forceinline__ void eval_half_tile(Lds& lds, const SdfPacked& pk, float x0, float x1, float x2) {
+  forward_hidden<false, true>(lds, pk, x0, x1, x2, nullptr);
+  sdf_head(lds, pk);
+  __syncthreads();
+}
+
 // Wave-level compaction: lanes with `keep` append `value` to out[] (count in *counter).  Call from wave 0 with
 // all 64 lanes active.
 __device__ __forceinline__ void wave_append(bool keep, int value, int* __restrict__ out, int* __restrict__ counter) {
@@ -83,8 +97,10 @@ trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* _
   int* __restrict__ lout = it == max_iters ? ws.slist : ws.list[(it + 1) & 1];
   int* cout = ws.counters + it + 1;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
-  for (int base = blockIdx.x * kWgPts; base < count; base += gridDim.x * kWgPts) {
-    const int e = base + 32 * (w & 1) + j;
+  const bool half = half_tiles(count);
+  const int tile_pts = half ? kHalfPts : kWgPts;
+  for (int base = blockIdx.x * tile_pts; base < count; base += gridDim.x * tile_pts) {
+    const int e = base + (half ? 0 : 32 * (w & 1)) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     if (e < count) {
       const int r = lin[e];
@@ -95,14 +111,14 @@ trace_step_kernel(SdfPacked pk, int it, int max_iters, float thr, const float* _
       x0 = pts[3 * r]; x1 = pts[3 * r + 1]; x2 = pts[3 * r + 2];
 #endif
     }
-    eval_tile(lds, pk, x0, x1, x2);
+    if (half) eval_half_tile(lds, pk, x0, x1, x2); else eval_tile(lds, pk, x0, x1, x2);
     if (threadIdx.x < kWgPts) {
       const int e2 = base + threadIdx.x;
       bool keep = false;
       int r = 0;
-      if (e2 < count) {
+      if (e2 < count && (int)threadIdx.x < tile_pts) {
         r = lin[e2];
-        const float v = read_sdf(lds, pk, threadIdx.x >> 5, threadIdx.x & 31);
+        const float v = read_sdf(lds, pk, half ? 1 : threadIdx.x >> 5, threadIdx.x & 31);
         sdf[r] = v;
         const bool work = work_mask[r] != 0;
         const float a = dis[r], amax = max_dis[r];
@@ -300,8 +316,10 @@ bisect_kernel(SdfPacked pk, int it, int final_pass, int max_bisect, float thr, i
   const int* __restrict__ flag_in = ws.flags + it * nchunks;
   int* __restrict__ flag_out = ws.flags + (it + 1) * nchunks;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
-  for (int base = blockIdx.x * kWgPts; base < count; base += gridDim.x * kWgPts) {
-    const int e = base + 32 * (w & 1) + j;
+  const bool half = half_tiles(count);
+  const int tile_pts = half ? kHalfPts : kWgPts;
+  for (int base = blockIdx.x * tile_pts; base < count; base += gridDim.x * tile_pts) {
+    const int e = base + (half ? 0 : 32 * (w & 1)) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
     bool active = false;
     if (e < count) {
@@ -314,13 +332,13 @@ bisect_kernel(SdfPacked pk, int it, int final_pass, int max_bisect, float thr, i
     }
     if (!__syncthreads_or(active)) continue;   // no ray of this tile is in a chunk that still iterates
     if (prof && threadIdx.x == 0)
-      atomicAdd(&g_trace_evals[2], (unsigned long long)(count - base < kWgPts ? count - base : kWgPts));
-    eval_tile(lds, pk, x0, x1, x2);
-    if (threadIdx.x < kWgPts) {
+      atomicAdd(&g_trace_evals[2], (unsigned long long)(count - base < tile_pts ? count - base : tile_pts));
+    if (half) eval_half_tile(lds, pk, x0, x1, x2); else eval_tile(lds, pk, x0, x1, x2);
+    if ((int)threadIdx.x < tile_pts) {
       const int e2 = base + threadIdx.x;
       if (e2 < count) {
         const int r = ws.blist[e2];
-        const float v = read_sdf(lds, pk, threadIdx.x >> 5, threadIdx.x & 31);
+        const float v = read_sdf(lds, pk, half ? 1 : threadIdx.x >> 5, threadIdx.x & 31);
         const int ch = min(r / chunk, nchunks - 1);
         float lo = ws.d_lo[r], hi = ws.d_hi[r];
         const float dm = (lo + hi) / 2.0f;
@@ -424,7 +442,8 @@ static int trace_enqueue(const void* packed, long n_rays, const float* ray_o, co
   const int prof_on = pir_prof_enabled();
   hipLaunchKernelGGL(trace_init_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, n_rays, ray_o, ray_d, min_dis,
                      points, distance, convergent, ws);
-  const long tiles = (n_rays + kWgPts - 1) / kWgPts;
+  // enough workgroups for one 32-entry tile each (the kernels switch to 64-entry tiles when the list is longer)
+  const long tiles = PIR_TRACE_HALF ? (n_rays + kHalfPts - 1) / kHalfPts : (n_rays + kWgPts - 1) / kWgPts;
   const long resident = 2L * pir_num_cus();
   const unsigned grid = (unsigned)(tiles < resident ? tiles : resident);
   for (int it = 0; it <= sphere_tracing_iters; ++it) {
