@@ -442,11 +442,23 @@ __global__ void __launch_bounds__(256)
 mlp_head_reduce_kernel(const float* __restrict__ partial, int n_out, float* __restrict__ gw, float* __restrict__ gb) {
   const int o = blockIdx.x, col = threadIdx.x;
   if (o >= n_out) return;
-  float s = 0.f, sg = 0.f;
-  for (int b = 0; b < kHeadBlocks; ++b) {
-    s += partial[((size_t)b * 4 + o) * 257 + col];
-    if (col == 0) sg += partial[((size_t)b * 4 + o) * 257 + 256];
+  // eight interleaved partial sums in a fixed order: the kernel runs on n_out <= 4 workgroups, so it is bound by the
+  // latency of its 512 dependent load-add steps unless several loads are in flight
+  float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sg = 0.f;
+  static_assert(kHeadBlocks % 8 == 0, "unrolled by 8");
+  for (int b = 0; b < kHeadBlocks; b += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s8[u] += partial[((size_t)(b + u) * 4 + o) * 257 + col];
   }
+  if (col == 0) {
+    float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < kHeadBlocks; b += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) g8[u] += partial[((size_t)(b + u) * 4 + o) * 257 + 256];
+    }
+    sg = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
+  }
+  const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   gw[o * 256 + col] += s;
   if (col == 0 && gb) gb[o] += sg;
 }
