@@ -17,20 +17,25 @@ __device__ __forceinline__ float ew_norm3(float a, float b, float c) {
   return sqrtf(ew_add(ew_add(ew_mul(a, a), ew_mul(b, b)), ew_mul(c, c)));
 }
 
+// HALF: 32 start points per workgroup in operand set 1 only (set 0's products are not issued): the walk is a chain of up
+// to 17 dependent forward + reverse passes, i.e. pure latency for the few dozen edge points of a training patch, and a
+// pass over one operand set is half the matrix work.  Chosen by the host when 32-point tiles fit the resident slots.
+template <bool HALF>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 edge_walk_kernel(SdfPacked pk, long n, float* __restrict__ points, const float* __restrict__ cam_o, int max_step,
                  float step_size, float dot_threshold, unsigned char* __restrict__ found,
                  f32x4* __restrict__ scratch_all) {
   __shared__ Lds lds;
+  constexpr int kPts = HALF ? 32 : kWgPts;
   __shared__ float s_x[kWgPts][3];
   __shared__ int s_state[kWgPts];     // 0 walking, 1 found, 2 padding
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
   f32x4* scratch = scratch_all + (size_t)blockIdx.x * kScratchWgF4;
-  const long ntiles = (n + kWgPts - 1) / kWgPts;
+  const long ntiles = (n + kPts - 1) / kPts;
   const float o0 = cam_o[0], o1 = cam_o[1], o2 = cam_o[2];
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long base = tile * kWgPts;
-    if (threadIdx.x < kWgPts) {
+    const long base = tile * kPts;
+    if (threadIdx.x < kPts) {
       const long q = base + threadIdx.x;
       const bool valid = q < n;
 #pragma unroll
@@ -39,23 +44,23 @@ edge_walk_kernel(SdfPacked pk, long n, float* __restrict__ points, const float* 
     }
     __syncthreads();
     for (int it = 0;; ++it) {
-      const int e = 32 * (w & 1) + j;
-      forward_hidden<true>(lds, pk, s_x[e][0], s_x[e][1], s_x[e][2], scratch);
+      const int e = HALF ? j : 32 * (w & 1) + j;          // HALF: point j lives in set 1 (encoded by wave 1)
+      forward_hidden<true, HALF>(lds, pk, s_x[e][0], s_x[e][1], s_x[e][2], scratch);
       sdf_head(lds, pk);
       __syncthreads();
       float val = 0.f;
-      if (threadIdx.x < kWgPts) val = read_sdf(lds, pk, threadIdx.x >> 5, threadIdx.x & 31);
-      normal_reverse(lds, pk, scratch);
+      if (threadIdx.x < kPts) val = read_sdf(lds, pk, HALF ? 1 : threadIdx.x >> 5, threadIdx.x & 31);
+      normal_reverse<HALF>(lds, pk, scratch);
       __syncthreads();
       bool walking = false;
-      if (threadIdx.x < kWgPts && s_state[threadIdx.x] == 0) {
-        const int t = threadIdx.x;
+      if (threadIdx.x < kPts && s_state[threadIdx.x] == 0) {
+        const int t = threadIdx.x, set = HALF ? 1 : t >> 5;
         const float x0 = s_x[t][0], x1 = s_x[t][1], x2 = s_x[t][2];
         float v0 = o0 - x0, v1 = o1 - x1, v2 = o2 - x2;
         const float vn = ew_norm3(v0, v1, v2) + 1e-10f;
         v0 /= vn; v1 /= vn; v2 /= vn;
-        float n0 = read_normal(lds, t >> 5, t & 31, 0), n1 = read_normal(lds, t >> 5, t & 31, 1),
-              n2 = read_normal(lds, t >> 5, t & 31, 2);
+        float n0 = read_normal(lds, set, t & 31, 0), n1 = read_normal(lds, set, t & 31, 1),
+              n2 = read_normal(lds, set, t & 31, 2);
         const float nn = ew_norm3(n0, n1, n2) + 1e-10f;
         n0 /= nn; n1 /= nn; n2 /= nn;
         const float dot = ew_add(ew_add(ew_mul(n0, v0), ew_mul(n1, v1)), ew_mul(n2, v2));
@@ -77,7 +82,7 @@ edge_walk_kernel(SdfPacked pk, long n, float* __restrict__ points, const float* 
       const int any = __syncthreads_or(walking ? 1 : 0);
       if (it >= max_step || !any) break;
     }
-    if (threadIdx.x < kWgPts) {
+    if (threadIdx.x < kPts) {
       const long q = base + threadIdx.x;
       if (q < n) {
 #pragma unroll
@@ -99,16 +104,21 @@ extern "C" int pir_edge_walk(const void* packed, long n, float* points, const fl
   if (n < 0 || max_step < 0 || max_step > 4096) return PIR_ERR_ARG;
   if (n == 0) return PIR_OK;
   if (!packed || !points || !cam_o || !found || !scratch) return PIR_ERR_ARG;
-  const long ntiles = (n + kWgPts - 1) / kWgPts;
   long nwg = (long)(scratch_bytes / kScratchWgBytes);
   if (nwg < 1) return PIR_ERR_SCRATCH;
   const long resident = 2L * pir_num_cus();
   if (nwg > resident) nwg = resident;
+  const bool half = (n + 31) / 32 <= nwg;       // one 32-point tile per workgroup slot covers the list
+  const long ntiles = half ? (n + 31) / 32 : (n + kWgPts - 1) / kWgPts;
   if (nwg > ntiles) nwg = ntiles;
   SdfPacked pk;
   pk.mats = (const f32x4*)packed;
   pk.vecs = (const float*)packed + (size_t)kPackedF4 * 4;
-  hipLaunchKernelGGL(edge_walk_kernel, dim3((unsigned)nwg), dim3(kThreads), 0, (hipStream_t)stream, pk, n, points, cam_o,
-                     max_step, step_size, dot_threshold, found, (f32x4*)scratch);
+  if (half)
+    hipLaunchKernelGGL(edge_walk_kernel<true>, dim3((unsigned)nwg), dim3(kThreads), 0, (hipStream_t)stream, pk, n, points,
+                       cam_o, max_step, step_size, dot_threshold, found, (f32x4*)scratch);
+  else
+    hipLaunchKernelGGL(edge_walk_kernel<false>, dim3((unsigned)nwg), dim3(kThreads), 0, (hipStream_t)stream, pk, n, points,
+                       cam_o, max_step, step_size, dot_threshold, found, (f32x4*)scratch);
   return pir_check_launch();
 }

@@ -200,6 +200,7 @@ __device__ __forceinline__ void pe_jacobian_t(const Lds& lds, const f32x16 (&acc
 
 // Reverse sweep for d sdf / d x.  Precondition: a7 in the LDS natural region, a0..a7 in scratch,
 // PE region intact.  Leaves the normal of (set, j) in lds.red[*][set][j][1..3] (sum the two wave slots).
+template <bool ONLY1 = false>
 __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, const f32x4* __restrict__ scratch) {
   const int lane = lane_id(), h = lane >> 5, w = wave_id();
   // q7 = w8 row (.) sigma(100 z7)
@@ -228,11 +229,11 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
 #pragma nounroll
   for (int l = 7; l >= 1; --l) {
     zero_acc(acc);
-    gemm_phase_pre<kTPW, false, true>(pk.mats, kRev[l], kTPW * w, lds, 0, acc, pre, l >= 2, kRev[l >= 2 ? l - 1 : l]);
+    gemm_phase_pre<kTPW, ONLY1, true>(pk.mats, kRev[l], kTPW * w, lds, 0, acc, pre, l >= 2, kRev[l >= 2 ? l - 1 : l]);
 #if PIR_PE_KSPLIT
-    if (l == 4) gemm_phase<1>(pk.mats, pe_khalf(kR4P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
+    if (l == 4) gemm_phase<1, ONLY1>(pk.mats, pe_khalf(kR4P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
 #else
-    if (l == 4 && w < 2) gemm_phase<1>(pk.mats, kR4P, w, lds, 0, accpe);
+    if (l == 4 && w < 2) gemm_phase<1, ONLY1>(pk.mats, kR4P, w, lds, 0, accpe);
 #endif
     PIR_STAMP(7);
     __syncthreads();
@@ -248,10 +249,10 @@ __device__ __forceinline__ void normal_reverse(Lds& lds, const SdfPacked& pk, co
 #if PIR_PE_KSPLIT
   // the two PE tiles over the two halves of K: wave w = (K half w / 2, tile w % 2); the encoding Jacobian is linear
   // in the accumulator, so every wave transforms its partial sum and read_normal adds the four
-  gemm_phase<1>(pk.mats, pe_khalf(kR0P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
+  gemm_phase<1, ONLY1>(pk.mats, pe_khalf(kR0P, w >> 1), w & 1, lds, (kActKB / 2) * (w >> 1), accpe);
   if ((w & 1) == 0) pe_jacobian_t<0>(lds, accpe, n); else pe_jacobian_t<1>(lds, accpe, n);
 #else
-  if (w < 2) gemm_phase<1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
+  if (w < 2) gemm_phase<1, ONLY1>(pk.mats, kR0P, w, lds, 0, accpe);   // the two PE tiles belong to waves 0 and 1
   if (w == 0) pe_jacobian_t<0>(lds, accpe, n); else if (w == 1) pe_jacobian_t<1>(lds, accpe, n);
 #endif
 #pragma unroll
