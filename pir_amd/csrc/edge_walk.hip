@@ -108,7 +108,7 @@ extern "C" int pir_edge_walk(const void* packed, long n, float* points, const fl
   if (nwg < 1) return PIR_ERR_SCRATCH;
   const long resident = 2L * pir_num_cus();
   if (nwg > resident) nwg = resident;
-  const bool half = (n + 31) / 32 <= nwg;       // one 32-point tile per workgroup slot covers the list
+  const bool half = (n + 31) / 32 <= (nwg < pir_num_cus() ? nwg : pir_num_cus());   // one 32-point tile per CU covers the list
   const long ntiles = half ? (n + 31) / 32 : (n + kWgPts - 1) / kWgPts;
   if (nwg > ntiles) nwg = ntiles;
   SdfPacked pk;

@@ -81,16 +81,23 @@ __global__ void pack_kernel(PackArgs a, float* __restrict__ mats, float* __restr
 }
 
 // --------------------------------------------------------------------------------- evaluation
+#ifndef PIR_EVAL_HALF
+#define PIR_EVAL_HALF 1      // 0: A/B build without the short-call mode
+#endif
 enum { kWantFeat = 1, kWantNormal = 2 };
 
-template <int FLAGS>
+// HALF: 32 points per workgroup in operand set 1 only (the products of set 0 are not issued): for calls so short that
+// 64-point tiles would leave most CUs idle (the hit points of a training patch), a pass is pure latency and one operand
+// set is half its matrix work.  The host picks it when 32-point tiles fit the resident workgroup slots.
+template <int FLAGS, bool HALF = false>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __restrict__ sdf, float* __restrict__ feat,
                 float* __restrict__ normal, f32x4* __restrict__ scratch_all) {
   __shared__ Lds lds;
   constexpr bool kNormal = (FLAGS & kWantNormal) != 0;
   const int lane = lane_id(), w = wave_id(), j = lane & 31;
-  const long ntiles = (M + kWgPts - 1) / kWgPts;
+  constexpr int kPts = HALF ? 32 : kWgPts;
+  const long ntiles = (M + kPts - 1) / kPts;
   f32x4* scratch = kNormal ? scratch_all + (size_t)blockIdx.x * kScratchWgF4 : nullptr;
 #ifdef PIR_STAMPS
   if (lane == 0) {
@@ -99,8 +106,8 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
   }
 #endif
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long base = tile * kWgPts;
-    const long P = base + 32 * (w & 1) + j;
+    const long base = tile * kPts;
+    const long P = base + (HALF ? 0 : 32 * (w & 1)) + j;
     float x0 = 0.f, x1 = 0.f, x2 = 0.f;
 #ifdef PIR_AB_X_SOA      // A/B (timing only): read the same buffer as three planes [3][M] (SoA, 4-byte coalesced)
     if (P < M) { x0 = x[P]; x1 = x[M + P]; x2 = x[2 * M + P]; }
@@ -109,22 +116,22 @@ sdf_eval_kernel(SdfPacked pk, const float* __restrict__ x, long M, float* __rest
 #else
     if (P < M) { x0 = x[3 * P]; x1 = x[3 * P + 1]; x2 = x[3 * P + 2]; }
 #endif
-    forward_hidden<kNormal>(lds, pk, x0, x1, x2, scratch);
+    forward_hidden<kNormal, HALF>(lds, pk, x0, x1, x2, scratch);
     sdf_head(lds, pk);
-    if (FLAGS & kWantFeat) feature_head(lds, pk, feat, base, M);
+    if (FLAGS & kWantFeat) feature_head<HALF>(lds, pk, feat, base, M);
     __syncthreads();
-    if (threadIdx.x < kWgPts) {
+    if (threadIdx.x < kPts) {
       const long Q = base + threadIdx.x;
-      if (Q < M) sdf[Q] = read_sdf(lds, pk, threadIdx.x >> 5, threadIdx.x & 31);
+      if (Q < M) sdf[Q] = read_sdf(lds, pk, HALF ? 1 : threadIdx.x >> 5, threadIdx.x & 31);
     }
     if (kNormal) {
-      normal_reverse(lds, pk, scratch);
+      normal_reverse<HALF>(lds, pk, scratch);
       __syncthreads();
-      if (threadIdx.x < kWgPts) {
+      if (threadIdx.x < kPts) {
         const long Q = base + threadIdx.x;
         if (Q < M) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) normal[3 * Q + c] = read_normal(lds, threadIdx.x >> 5, threadIdx.x & 31, c);
+          for (int c = 0; c < 3; ++c) normal[3 * Q + c] = read_normal(lds, HALF ? 1 : threadIdx.x >> 5, threadIdx.x & 31, c);
         }
       }
     }
@@ -200,15 +207,19 @@ int pir_sdf_forward(const void* packed, const float* x, long M, float* sdf, floa
   if (M < 0 || !packed || (M > 0 && (!x || !sdf))) return PIR_ERR_ARG;
   if (M == 0) return PIR_OK;
   SdfPacked pk = make_packed(packed);
-  const long ntiles = (M + kWgPts - 1) / kWgPts;
+  // short call: one 32-point tile per CU (measured: 250 -> 157 us up to 8 192 points; two co-resident half tiles per
+  // CU are no faster than one full tile alone, so longer calls keep the 64-point tiles)
+  const bool half = PIR_EVAL_HALF && (M + 31) / 32 <= pir_num_cus();
+  const long ntiles = half ? (M + 31) / 32 : (M + kWgPts - 1) / kWgPts;
   dim3 grid((unsigned)(ntiles < (1L << 30) ? ntiles : (1L << 30)));
   PirProfScope prof(feat ? PIR_K_SDF_EVAL_FEAT : PIR_K_SDF_EVAL, (double)M, stream);
-  if (feat)
-    hipLaunchKernelGGL(sdf_eval_kernel<kWantFeat>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf, feat,
-                       (float*)nullptr, (f32x4*)nullptr);
-  else
-    hipLaunchKernelGGL(sdf_eval_kernel<0>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf,
-                       (float*)nullptr, (float*)nullptr, (f32x4*)nullptr);
+#define PIR_EVAL_LAUNCH(FLAGS, HALF, FEAT, NORMAL, SCRATCH)                                                         \
+  hipLaunchKernelGGL((sdf_eval_kernel<FLAGS, HALF>), grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf, FEAT, \
+                     NORMAL, SCRATCH)
+  if (feat) { if (half) PIR_EVAL_LAUNCH(kWantFeat, true, feat, (float*)nullptr, (f32x4*)nullptr);
+              else PIR_EVAL_LAUNCH(kWantFeat, false, feat, (float*)nullptr, (f32x4*)nullptr); }
+  else { if (half) PIR_EVAL_LAUNCH(0, true, (float*)nullptr, (float*)nullptr, (f32x4*)nullptr);
+         else PIR_EVAL_LAUNCH(0, false, (float*)nullptr, (float*)nullptr, (f32x4*)nullptr); }
   return pir_check_launch();
 }
 
@@ -216,21 +227,21 @@ int pir_sdf_get_all(const void* packed, const float* x, long M, float* sdf, floa
                     size_t scratch_bytes, void* stream) {
   if (M < 0 || !packed || (M > 0 && (!x || !sdf || !normal || !scratch))) return PIR_ERR_ARG;
   if (M == 0) return PIR_OK;
-  const long ntiles = (M + kWgPts - 1) / kWgPts;
   long nwg = (long)(scratch_bytes / kScratchWgBytes);
   if (nwg < 1) return PIR_ERR_SCRATCH;
   const long resident = 2L * pir_num_cus();
   if (nwg > resident) nwg = resident;
+  const bool half = PIR_EVAL_HALF && (M + 31) / 32 <= (nwg < pir_num_cus() ? nwg : pir_num_cus());   // as in pir_sdf_forward
+  const long ntiles = half ? (M + 31) / 32 : (M + kWgPts - 1) / kWgPts;
   if (nwg > ntiles) nwg = ntiles;
   SdfPacked pk = make_packed(packed);
   dim3 grid((unsigned)nwg);
   PirProfScope prof(feat ? PIR_K_SDF_GETALL_FEAT : PIR_K_SDF_GETALL, (double)M, stream);
-  if (feat)
-    hipLaunchKernelGGL(sdf_eval_kernel<kWantFeat | kWantNormal>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x,
-                       M, sdf, feat, normal, (f32x4*)scratch);
-  else
-    hipLaunchKernelGGL(sdf_eval_kernel<kWantNormal>, grid, dim3(kThreads), 0, (hipStream_t)stream, pk, x, M, sdf,
-                       (float*)nullptr, normal, (f32x4*)scratch);
+  if (feat) { if (half) PIR_EVAL_LAUNCH(kWantFeat | kWantNormal, true, feat, normal, (f32x4*)scratch);
+              else PIR_EVAL_LAUNCH(kWantFeat | kWantNormal, false, feat, normal, (f32x4*)scratch); }
+  else { if (half) PIR_EVAL_LAUNCH(kWantNormal, true, (float*)nullptr, normal, (f32x4*)scratch);
+         else PIR_EVAL_LAUNCH(kWantNormal, false, (float*)nullptr, normal, (f32x4*)scratch); }
+#undef PIR_EVAL_LAUNCH
   return pir_check_launch();
 }
 

@@ -119,17 +119,18 @@ __device__ __forceinline__ float read_sdf(const Lds& lds, const SdfPacked& pk, i
   return s;
 }
 
-// lin8 rows 1..256 (+bias) -> feat[(base + 32*set + j) * 256 + f]
+// lin8 rows 1..256 (+bias) -> feat[(base + 32*set + j) * 256 + f]   (ONLY1: set 1 only, point base + j)
+template <bool ONLY1 = false>
 __device__ __forceinline__ void feature_head(const Lds& lds, const SdfPacked& pk, float* __restrict__ feat,
                                              long base, long M) {
   const int lane = lane_id(), h = lane >> 5, j = lane & 31, w = wave_id();
   f32x16 acc[kSets][kTPW];
   zero_acc(acc);
-  gemm_phase<kTPW>(pk.mats, kF8, kTPW * w, lds, 0, acc);
+  gemm_phase<kTPW, ONLY1>(pk.mats, kF8, kTPW * w, lds, 0, acc);
   const float* bias = pk.vecs + kVecBias + 256 * 8;
 #pragma unroll
-  for (int s = 0; s < kSets; ++s) {
-    const long P = base + 32 * s + j;
+  for (int s = ONLY1 ? 1 : 0; s < kSets; ++s) {
+    const long P = base + (ONLY1 ? 0 : 32 * s) + j;
     if (P < M) {
 #pragma unroll
       for (int t = 0; t < kTPW; ++t) {
