@@ -47,9 +47,20 @@ struct MlpPlan {
   int rprod_out;     //   W_out^T over the n_out outputs (n_out / 8 k-blocks; n_out > 4 only, n_out % 8 == 0)
 };
 
+// Short calls (at most one 32-point tile per CU: the hit points of a 64 x 64 patch): HALF puts 32 points per workgroup
+// into operand set 1 only and does not issue set 0's products -- twice the CUs busy, half the matrix work per tile.
+// Same arithmetic per point, so the results do not depend on the mode.
+#ifndef PIR_MLP_HALF
+#define PIR_MLP_HALF 1         // 0: A/B build with 64-point tiles only
+#endif
+template <bool HALF> constexpr int kS0 = HALF ? 1 : 0;           // first operand set in use
+template <bool HALF> constexpr int kPts = HALF ? 32 : kWgPts;    // points per tile
+template <bool HALF> __device__ __forceinline__ int tile_pt(int s, int j) { return HALF ? j : 32 * s + j; }
+
 // x-slice of both operand sets -> activation region, then acc += W[:, slice] x slice, for every slice of the input.
 // Leaves with all waves past their last read of the final slice NOT guaranteed: callers synchronise before they
 // overwrite the activation region.
+template <bool HALF>
 __device__ __forceinline__ void input_gemm(Lds& lds, const f32x4* __restrict__ mats, int prod_off, int kin_kb,
                                            const float* __restrict__ X, long base, long P,
                                            f32x16 (&acc)[kSets][kTPW]) {
@@ -60,20 +71,20 @@ __device__ __forceinline__ void input_gemm(Lds& lds, const f32x4* __restrict__ m
     __syncthreads();   // every read of the previous content of the activation region is done
     for (int kb = w; kb < n; kb += kWaves) {
 #pragma unroll
-      for (int s = 0; s < kSets; ++s) {
-        const long Pt = base + 32 * s + j;
+      for (int s = kS0<HALF>; s < kSets; ++s) {
+        const long Pt = base + tile_pt<HALF>(s, j);
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (Pt < P) v = *reinterpret_cast<const f32x4*>(X + (size_t)Pt * ldx + 8 * (c0 + kb) + 4 * h);
         lds.act[s][kb][lane] = v;
       }
     }
     __syncthreads();
-    gemm_phase<kTPW>(mats, Prod{prod_off + c0 * 8 * kTileKB, n, 8}, kTPW * w, lds, 0, acc);
+    gemm_phase<kTPW, HALF>(mats, Prod{prod_off + c0 * 8 * kTileKB, n, 8}, kTPW * w, lds, 0, acc);
   }
 }
 
 // a = relu(acc + bias) -> LDS activation region of both sets; optionally also to a [row][256] array.
-template <bool STORE>
+template <bool STORE, bool HALF>
 __device__ __forceinline__ void epilogue_relu(Lds& lds, f32x16 (&acc)[kSets][kTPW], const float* __restrict__ bias,
                                               float* __restrict__ H, long row0, long nrows) {
   const int lane = lane_id(), h = lane >> 5, w = wave_id(), j = lane & 31;
@@ -84,13 +95,13 @@ __device__ __forceinline__ void epilogue_relu(Lds& lds, f32x16 (&acc)[kSets][kTP
     for (int g = 0; g < 4; ++g) {
       const f32x4 b = load_feat4(bias, T, g, h);
 #pragma unroll
-      for (int s = 0; s < kSets; ++s) {
+      for (int s = kS0<HALF>; s < kSets; ++s) {
         f32x4 a;
 #pragma unroll
         for (int c = 0; c < 4; ++c) a[c] = fmaxf(acc[s][t][4 * g + c] + b[c], 0.f);
         lds.act[s][4 * T + g][lane] = a;
         if (STORE) {
-          const long r = row0 + 32 * s + j;
+          const long r = row0 + tile_pt<HALF>(s, j);
           if (r < nrows) *reinterpret_cast<f32x4*>(H + (size_t)r * 256 + 32 * T + 8 * g + 4 * h) = a;
         }
       }
@@ -98,39 +109,40 @@ __device__ __forceinline__ void epilogue_relu(Lds& lds, f32x16 (&acc)[kSets][kTP
   }
 }
 
-// All hidden layers of one 64-point tile; leaves the last activations in LDS (all waves synchronised).
+// All hidden layers of one tile; leaves the last activations in LDS (all waves synchronised).
 // STORE: activations of layer l also go to Hs + l * h_stride ([row][256], rows relative to row0 = base - chunk_base).
-template <bool STORE>
+template <bool STORE, bool HALF>
 __device__ __forceinline__ void mlp_hidden(Lds& lds, const f32x4* __restrict__ mats, const float* __restrict__ vecs,
                                            const MlpPlan& pl, const float* __restrict__ X, long base, long P,
                                            float* __restrict__ Hs, size_t h_stride, long row0, long nrows) {
   const int w = wave_id();
   f32x16 acc[kSets][kTPW];
   zero_acc(acc);
-  input_gemm(lds, mats, pl.prod_in, pl.kin_kb, X, base, P, acc);
+  input_gemm<HALF>(lds, mats, pl.prod_in, pl.kin_kb, X, base, P, acc);
   __syncthreads();
-  epilogue_relu<STORE>(lds, acc, vecs + pl.bias_off, Hs, row0, nrows);
+  epilogue_relu<STORE, HALF>(lds, acc, vecs + pl.bias_off, Hs, row0, nrows);
   __syncthreads();
 #pragma nounroll
   for (int l = 1; l < pl.n_hidden; ++l) {
     zero_acc(acc);
-    gemm_phase<kTPW>(mats, Prod{pl.prod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
-    if (l == pl.skip) input_gemm(lds, mats, pl.prod_skip_x, pl.kin_kb, X, base, P, acc);
+    gemm_phase<kTPW, HALF>(mats, Prod{pl.prod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
+    if (l == pl.skip) input_gemm<HALF>(lds, mats, pl.prod_skip_x, pl.kin_kb, X, base, P, acc);
     __syncthreads();
-    epilogue_relu<STORE>(lds, acc, vecs + pl.bias_off + 256 * l, Hs + (size_t)l * h_stride, row0, nrows);
+    epilogue_relu<STORE, HALF>(lds, acc, vecs + pl.bias_off + 256 * l, Hs + (size_t)l * h_stride, row0, nrows);
     __syncthreads();
   }
 }
 
+template <bool HALF>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 mlp_eval_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, MlpPlan pl,
                 const float* __restrict__ X, long P, float* __restrict__ out) {
   __shared__ Lds lds;
   const int lane = lane_id(), w = wave_id(), j = lane & 31, h = lane >> 5;
-  const long ntiles = (P + kWgPts - 1) / kWgPts;
+  const long ntiles = (P + kPts<HALF> - 1) / kPts<HALF>;
   for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long base = tile * kWgPts;
-    mlp_hidden<false>(lds, mats, vecs, pl, X, base, P, nullptr, 0, 0, 0);
+    const long base = tile * kPts<HALF>;
+    mlp_hidden<false, HALF>(lds, mats, vecs, pl, X, base, P, nullptr, 0, 0, 0);
     if (pl.n_out <= 4) {
       for (int o = 0; o < pl.n_out; ++o) {
         float part[kSets];
@@ -138,13 +150,14 @@ mlp_eval_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, 
         if (lane < 32) { lds.red[w][0][lane][o] = part[0]; lds.red[w][1][lane][o] = part[1]; }
       }
       __syncthreads();
-      if (threadIdx.x < kWgPts) {
+      if (threadIdx.x < kPts<HALF>) {
         const long Q = base + threadIdx.x;
+        const int set = HALF ? 1 : threadIdx.x >> 5;
         if (Q < P) {
           for (int o = 0; o < pl.n_out; ++o) {
             float s = vecs[pl.out_bias_off + o];
 #pragma unroll
-            for (int ww = 0; ww < kWaves; ++ww) s += lds.red[ww][threadIdx.x >> 5][threadIdx.x & 31][o];
+            for (int ww = 0; ww < kWaves; ++ww) s += lds.red[ww][set][threadIdx.x & 31][o];
             out[Q * pl.n_out + o] = s;
           }
         }
@@ -154,11 +167,11 @@ mlp_eval_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, 
       for (int p = 0; p < passes; ++p) {
         f32x16 acc[kSets][kTPW];
         zero_acc(acc);
-        gemm_phase<kTPW>(mats, Prod{pl.prod_out + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
+        gemm_phase<kTPW, HALF>(mats, Prod{pl.prod_out + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
         const float* bias = vecs + pl.out_bias_off + 256 * p;
 #pragma unroll
-        for (int s = 0; s < kSets; ++s) {
-          const long Q = base + 32 * s + j;
+        for (int s = kS0<HALF>; s < kSets; ++s) {
+          const long Q = base + tile_pt<HALF>(s, j);
 #pragma unroll
           for (int t = 0; t < kTPW; ++t) {
             const int T = kTPW * w + t;
@@ -183,7 +196,7 @@ mlp_eval_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, 
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------
-// Per 64-point tile: recompute the hidden activations (stored to H_l for the weight-gradient GEMM), then
+// Per tile: recompute the hidden activations (stored to H_l for the weight-gradient GEMM), then
 //   dz_{L-1} = (W_out^T g_out) (.) [a_{L-1} > 0]            (n_out <= 4: a rank-n_out update on the VALU)
 //   dz_{l-1} = (W_l^T dz_l) (.) [a_{l-1} > 0]               (transposed products on MFMA)
 //   g_x      = W_0^T dz_0 (+ W_skip,x^T dz_skip)
@@ -191,13 +204,14 @@ mlp_eval_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, 
 struct MlpBwdScratch { float* H; float* DZ; size_t stride; };   // layer l at + l * stride, [chunk rows][256]
 
 // acc (input-gradient tiles of one pass of 256 columns) -> g_x[P][8 kin_kb], optionally accumulating
+template <bool HALF>
 __device__ __forceinline__ void store_gx_pass(const f32x16 (&acc)[kSets][kTPW], float* __restrict__ g_x, int kin_kb,
                                               int pass, long base, long P, bool accumulate) {
   const int lane = lane_id(), w = wave_id(), j = lane & 31, h = lane >> 5;
   const size_t ldx = (size_t)8 * kin_kb;
 #pragma unroll
-  for (int s = 0; s < kSets; ++s) {
-    const long Q = base + 32 * s + j;
+  for (int s = kS0<HALF>; s < kSets; ++s) {
+    const long Q = base + tile_pt<HALF>(s, j);
 #pragma unroll
     for (int t = 0; t < kTPW; ++t) {
       const int T = kTPW * w + t;
@@ -217,28 +231,29 @@ __device__ __forceinline__ void store_gx_pass(const f32x16 (&acc)[kSets][kTPW], 
   }
 }
 
+template <bool HALF>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, MlpPlan pl,
                      const float* __restrict__ X, const float* __restrict__ g_out, long chunk_base, int chunk_n,
                      long P, MlpBwdScratch sc, float* __restrict__ g_x) {
   __shared__ Lds lds;
   const int lane = lane_id(), w = wave_id(), j = lane & 31, h = lane >> 5;
-  const int ntiles = (chunk_n + kWgPts - 1) / kWgPts;
+  const int ntiles = (chunk_n + kPts<HALF> - 1) / kPts<HALF>;
   const int L = pl.n_hidden;
   const int xpasses = (pl.kin_kb + kActKB - 1) / kActKB;
   const long chunk_end = chunk_base + chunk_n;
-  const long rpad = (long)ntiles * kWgPts;   // rows of the chunk's scratch arrays that this launch defines (zeros / finite
+  const long rpad = (long)ntiles * kPts<HALF>;   // rows of the chunk's scratch arrays that this launch defines (zeros / finite
                                              // values beyond chunk_n: the weight-gradient GEMM reads whole 32-row steps)
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long base = chunk_base + (long)tile * kWgPts;
-    const long row0 = (long)tile * kWgPts;
-    mlp_hidden<true>(lds, mats, vecs, pl, X, base, chunk_end, sc.H, sc.stride, row0, rpad);
+    const long base = chunk_base + (long)tile * kPts<HALF>;
+    const long row0 = (long)tile * kPts<HALF>;
+    mlp_hidden<true, HALF>(lds, mats, vecs, pl, X, base, chunk_end, sc.H, sc.stride, row0, rpad);
     f32x16 acc[kSets][kTPW];
     if (pl.n_out > 4) {
       // ---- wide output layer (DINO field): dz_{L-1} = (W_out^T g_out) (.) [a_{L-1} > 0] on MFMA, g_out rows streamed
       // through the activation region like an input (the mask comes from the stored H_{L-1})
       zero_acc(acc);
-      input_gemm(lds, mats, pl.rprod_out, pl.n_out / 8, g_out, base, chunk_end, acc);
+      input_gemm<HALF>(lds, mats, pl.rprod_out, pl.n_out / 8, g_out, base, chunk_end, acc);
       __syncthreads();
       const float* Hl = sc.H + (size_t)(L - 1) * sc.stride;
       float* DZl = sc.DZ + (size_t)(L - 1) * sc.stride;
@@ -248,8 +263,8 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-          for (int s = 0; s < kSets; ++s) {
-            const size_t off = (size_t)(row0 + 32 * s + j) * 256 + 32 * T + 8 * g + 4 * h;
+          for (int s = kS0<HALF>; s < kSets; ++s) {
+            const size_t off = (size_t)(row0 + tile_pt<HALF>(s, j)) * 256 + 32 * T + 8 * g + 4 * h;
             const f32x4 a = *reinterpret_cast<const f32x4*>(Hl + off);
             f32x4 dz;
 #pragma unroll
@@ -263,8 +278,8 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
     // ---- output layer: dz_{L-1} from g_out, masked by the activations still in LDS
     float go[kSets][4];
 #pragma unroll
-    for (int s = 0; s < kSets; ++s) {
-      const long Q = base + 32 * s + j;
+    for (int s = kS0<HALF>; s < kSets; ++s) {
+      const long Q = base + tile_pt<HALF>(s, j);
 #pragma unroll
       for (int o = 0; o < 4; ++o) go[s][o] = (o < pl.n_out && Q < chunk_end) ? g_out[Q * pl.n_out + o] : 0.f;
     }
@@ -280,7 +295,7 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
           if (o < pl.n_out) wv[o] = load_feat4(vecs + pl.head_off + 256 * o, T, g, h);
         }
 #pragma unroll
-        for (int s = 0; s < kSets; ++s) {
+        for (int s = kS0<HALF>; s < kSets; ++s) {
           const f32x4 a = lds.act[s][4 * T + g][lane];
           f32x4 dz;
 #pragma unroll
@@ -289,7 +304,7 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
             dz[c] = a[c] > 0.f ? d : 0.f;
           }
           lds.act[s][4 * T + g][lane] = dz;
-          const long r = row0 + 32 * s + j;
+          const long r = row0 + tile_pt<HALF>(s, j);
           *reinterpret_cast<f32x4*>(sc.DZ + (size_t)(L - 1) * sc.stride + (size_t)r * 256 + 32 * T + 8 * g + 4 * h) = dz;
         }
       }
@@ -302,12 +317,12 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
       if (l == pl.skip && g_x) {   // the x share of the skip layer's input gradient
         for (int p = 0; p < xpasses; ++p) {
           zero_acc(acc);
-          gemm_phase<kTPW>(mats, Prod{pl.rprod_skip_x + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
-          store_gx_pass(acc, g_x, pl.kin_kb, p, base, chunk_end, false);
+          gemm_phase<kTPW, HALF>(mats, Prod{pl.rprod_skip_x + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
+          store_gx_pass<HALF>(acc, g_x, pl.kin_kb, p, base, chunk_end, false);
         }
       }
       zero_acc(acc);
-      gemm_phase<kTPW>(mats, Prod{pl.rprod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
+      gemm_phase<kTPW, HALF>(mats, Prod{pl.rprod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
       __syncthreads();   // every read of dz_l is done
       const float* Hl = sc.H + (size_t)(l - 1) * sc.stride;
       float* DZl = sc.DZ + (size_t)(l - 1) * sc.stride;
@@ -317,8 +332,8 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
 #pragma unroll
-          for (int s = 0; s < kSets; ++s) {
-            const long r = row0 + 32 * s + j;
+          for (int s = kS0<HALF>; s < kSets; ++s) {
+            const long r = row0 + tile_pt<HALF>(s, j);
             const f32x4 a = *reinterpret_cast<const f32x4*>(Hl + (size_t)r * 256 + 32 * T + 8 * g + 4 * h);
             f32x4 dz;
 #pragma unroll
@@ -334,8 +349,8 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
     if (g_x) {
       for (int p = 0; p < xpasses; ++p) {
         zero_acc(acc);
-        gemm_phase<kTPW>(mats, Prod{pl.rprod_in + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
-        store_gx_pass(acc, g_x, pl.kin_kb, p, base, chunk_end, pl.skip >= 1);
+        gemm_phase<kTPW, HALF>(mats, Prod{pl.rprod_in + p * kActKB * 8 * kTileKB, kActKB, 8}, kTPW * w, lds, 0, acc);
+        store_gx_pass<HALF>(acc, g_x, pl.kin_kb, p, base, chunk_end, pl.skip >= 1);
       }
     }
     // the next tile's first slice load synchronises before the activation region is overwritten
@@ -347,6 +362,7 @@ mlp_bwd_sweep_kernel(const f32x4* __restrict__ mats, const float* __restrict__ v
 //   t_0 = m_0 (.) W_0 gbar_x,   t_l = m_l (.) (W_l t_{l-1} [+ W_skip,x gbar_x]),
 // so d/dW_l = dz_l t_{l-1}^T (t_{-1} = gbar_x), d/dW_out = g_out t_{L-1}^T, d/dg_out = W_out t_{L-1}, and nothing
 // reaches x or the biases.  This kernel is the forward kernel on gbar_x without biases, masked by the stored H_l.
+template <bool HALF>
 __device__ __forceinline__ void epilogue_mask(Lds& lds, f32x16 (&acc)[kSets][kTPW], const float* __restrict__ Hl,
                                               float* __restrict__ Tl, long row0) {
   const int lane = lane_id(), h = lane >> 5, w = wave_id(), j = lane & 31;
@@ -356,8 +372,8 @@ __device__ __forceinline__ void epilogue_mask(Lds& lds, f32x16 (&acc)[kSets][kTP
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
-      for (int s = 0; s < kSets; ++s) {
-        const size_t off = (size_t)(row0 + 32 * s + j) * 256 + 32 * T + 8 * g + 4 * h;
+      for (int s = kS0<HALF>; s < kSets; ++s) {
+        const size_t off = (size_t)(row0 + tile_pt<HALF>(s, j)) * 256 + 32 * T + 8 * g + 4 * h;
         const f32x4 a = *reinterpret_cast<const f32x4*>(Hl + off);
         f32x4 tv;
 #pragma unroll
@@ -369,30 +385,31 @@ __device__ __forceinline__ void epilogue_mask(Lds& lds, f32x16 (&acc)[kSets][kTP
   }
 }
 
+template <bool HALF>
 __global__ void __launch_bounds__(kThreads, kWavesPerSimd)
 mlp_tangent_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vecs, MlpPlan pl,
                    const float* __restrict__ GX, long chunk_base, int chunk_n, const float* __restrict__ H,
                    float* __restrict__ Tn, size_t stride, float* __restrict__ ghat_out) {
   __shared__ Lds lds;
   const int lane = lane_id(), w = wave_id();
-  const int ntiles = (chunk_n + kWgPts - 1) / kWgPts;
+  const int ntiles = (chunk_n + kPts<HALF> - 1) / kPts<HALF>;
   const long chunk_end = chunk_base + chunk_n;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long base = chunk_base + (long)tile * kWgPts;
-    const long row0 = (long)tile * kWgPts;
+    const long base = chunk_base + (long)tile * kPts<HALF>;
+    const long row0 = (long)tile * kPts<HALF>;
     f32x16 acc[kSets][kTPW];
     zero_acc(acc);
-    input_gemm(lds, mats, pl.prod_in, pl.kin_kb, GX, base, chunk_end, acc);
+    input_gemm<HALF>(lds, mats, pl.prod_in, pl.kin_kb, GX, base, chunk_end, acc);
     __syncthreads();
-    epilogue_mask(lds, acc, H, Tn, row0);
+    epilogue_mask<HALF>(lds, acc, H, Tn, row0);
     __syncthreads();
 #pragma nounroll
     for (int l = 1; l < pl.n_hidden; ++l) {
       zero_acc(acc);
-      gemm_phase<kTPW>(mats, Prod{pl.prod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
-      if (l == pl.skip) input_gemm(lds, mats, pl.prod_skip_x, pl.kin_kb, GX, base, chunk_end, acc);
+      gemm_phase<kTPW, HALF>(mats, Prod{pl.prod_h[l], kActKB, 8}, kTPW * w, lds, 0, acc);
+      if (l == pl.skip) input_gemm<HALF>(lds, mats, pl.prod_skip_x, pl.kin_kb, GX, base, chunk_end, acc);
       __syncthreads();
-      epilogue_mask(lds, acc, H + (size_t)l * stride, Tn + (size_t)l * stride, row0);
+      epilogue_mask<HALF>(lds, acc, H + (size_t)l * stride, Tn + (size_t)l * stride, row0);
       __syncthreads();
     }
     for (int o = 0; o < pl.n_out; ++o) {
@@ -401,13 +418,14 @@ mlp_tangent_kernel(const f32x4* __restrict__ mats, const float* __restrict__ vec
       if (lane < 32) { lds.red[w][0][lane][o] = part[0]; lds.red[w][1][lane][o] = part[1]; }
     }
     __syncthreads();
-    if (threadIdx.x < kWgPts) {
+    if (threadIdx.x < kPts<HALF>) {
       const long Q = base + threadIdx.x;
+      const int set = HALF ? 1 : threadIdx.x >> 5;
       if (Q < chunk_end) {
         for (int o = 0; o < pl.n_out; ++o) {
           float sacc = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < kWaves; ++ww) sacc += lds.red[ww][threadIdx.x >> 5][threadIdx.x & 31][o];
+          for (int ww = 0; ww < kWaves; ++ww) sacc += lds.red[ww][set][threadIdx.x & 31][o];
           ghat_out[Q * pl.n_out + o] = sacc;
         }
       }
@@ -463,6 +481,9 @@ mlp_head_reduce_kernel(const float* __restrict__ partial, int n_out, float* __re
   if (col == 0 && gb) gb[o] += sg;
 }
 
+// one 32-point tile per CU covers the call: short-call mode
+static bool mlp_half(long n) { return PIR_MLP_HALF && (n + 31) / 32 <= (long)pir_num_cus(); }
+
 static bool plan_ok(const MlpPlan& pl) {
   if (pl.kin_kb < 1 || pl.n_hidden < 1 || pl.n_hidden > 8 || pl.n_out < 1) return false;
   if (pl.skip != -1 && (pl.skip < 1 || pl.skip >= pl.n_hidden)) return false;
@@ -499,11 +520,15 @@ int pir_mlp_forward(const void* packed, size_t mats_floats, const PirMlpPlan* pl
   if (!X || !out) return PIR_ERR_ARG;
   const f32x4* mats = (const f32x4*)packed;
   const float* vecs = (const float*)packed + mats_floats;
-  const long ntiles = (P + kWgPts - 1) / kWgPts;
+  const bool half = mlp_half(P);
+  const long ntiles = half ? (P + 31) / 32 : (P + kWgPts - 1) / kWgPts;
   const long resident = 2L * pir_num_cus();
+  const dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
   PirProfScope prof(PIR_K_MLP_FWD, (double)P, stream);
-  hipLaunchKernelGGL(mlp_eval_kernel, dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(kThreads), 0,
-                     (hipStream_t)stream, mats, vecs, pl, X, P, out);
+  if (half)
+    hipLaunchKernelGGL(mlp_eval_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, mats, vecs, pl, X, P, out);
+  else
+    hipLaunchKernelGGL(mlp_eval_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, mats, vecs, pl, X, P, out);
   return pir_check_launch();
 }
 
@@ -544,12 +569,18 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
   for (long base = 0; base < P; base += cap) {
     const int n = (int)(P - base < cap ? P - base : cap);
     const int n_rows = (n + 31) / 32 * 32;
-    const int ntiles = (n + kWgPts - 1) / kWgPts;
+    const bool half = mlp_half(n);
+    const int ntiles = half ? (n + 31) / 32 : (n + kWgPts - 1) / kWgPts;
     const long resident = 2L * pir_num_cus();
+    const dim3 grid((unsigned)(ntiles < resident ? ntiles : resident));
     {
       PirProfScope prof(PIR_K_MLP_BWD, (double)n, stream_);
-      hipLaunchKernelGGL(mlp_bwd_sweep_kernel, dim3((unsigned)(ntiles < resident ? ntiles : resident)), dim3(kThreads), 0,
-                         stream, mats, vecs, pl, X, g_out, base, n, P, sc, g_x);
+      if (half)
+        hipLaunchKernelGGL(mlp_bwd_sweep_kernel<true>, grid, dim3(kThreads), 0, stream, mats, vecs, pl, X, g_out, base, n, P,
+                           sc, g_x);
+      else
+        hipLaunchKernelGGL(mlp_bwd_sweep_kernel<false>, grid, dim3(kThreads), 0, stream, mats, vecs, pl, X, g_out, base, n, P,
+                           sc, g_x);
     }
     int rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
@@ -643,15 +674,23 @@ int pir_mlp_backward_tangent(const void* packed, size_t mats_floats, const PirMl
   for (long base = 0; base < P; base += cap) {
     const int n = (int)(P - base < cap ? P - base : cap);
     const int n_rows = (n + 31) / 32 * 32;
-    const int ntiles = (n + kWgPts - 1) / kWgPts;
+    const bool half = mlp_half(n);
+    const int ntiles = half ? (n + 31) / 32 : (n + kWgPts - 1) / kWgPts;
     const long resident = 2L * pir_num_cus();
     const unsigned grid = (unsigned)(ntiles < resident ? ntiles : resident);
     {
       PirProfScope prof(PIR_K_MLP_BWD, (double)n, stream_);
-      hipLaunchKernelGGL(mlp_bwd_sweep_kernel, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, X, g_out, base, n, P,
-                         sc, (float*)nullptr);
-      hipLaunchKernelGGL(mlp_tangent_kernel, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, gbar_x, base, n,
-                         (const float*)sc.H, Tn, sc.stride, ghat_out);
+      if (half) {
+        hipLaunchKernelGGL(mlp_bwd_sweep_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, X, g_out, base,
+                           n, P, sc, (float*)nullptr);
+        hipLaunchKernelGGL(mlp_tangent_kernel<true>, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, gbar_x, base, n,
+                           (const float*)sc.H, Tn, sc.stride, ghat_out);
+      } else {
+        hipLaunchKernelGGL(mlp_bwd_sweep_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, X, g_out, base,
+                           n, P, sc, (float*)nullptr);
+        hipLaunchKernelGGL(mlp_tangent_kernel<false>, dim3(grid), dim3(kThreads), 0, stream, mats, vecs, pl, gbar_x, base, n,
+                           (const float*)sc.H, Tn, sc.stride, ghat_out);
+      }
     }
     int rc = pir_check_launch();
     if (rc != PIR_OK) return rc;

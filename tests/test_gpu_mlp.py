@@ -28,7 +28,7 @@ def _call(net, name, pts, nrm, geo, dino):
     return net(pts, nrm, None, geo, dino)
 
 
-@pytest.mark.parametrize("P", [0, 1, 63, 64, 1000, 70001])
+@pytest.mark.parametrize("P", [0, 1, 33, 63, 64, 1000, 8193, 70001])   # up to 8192 points: 32-point tiles
 def test_material_forward_matches_eager(P):
     from pir_amd import scene, mlp_hip
     _, mats, dinonet = scene.build_networks(seed=3, device="cuda")
@@ -73,7 +73,7 @@ def test_material_forward_matches_oracle_and_repacks_after_update():
     assert rel_err(got2.cpu().numpy(), got.cpu().numpy()) > 1e-3
 
 
-@pytest.mark.parametrize("P", [1, 64, 1000])
+@pytest.mark.parametrize("P", [1, 33, 64, 1000])
 def test_material_backward_matches_eager(P):
     """Fused backward (recompute + sweeps + split-K weight gradients) against autograd on the eager expression:
     gradients of every parameter (through weight norm) and of every input."""
@@ -105,6 +105,42 @@ def test_material_backward_matches_eager(P):
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-5, (name, nm)
         for k in gp0:
             assert rel_err(gp0[k].cpu().numpy(), gp1[k].cpu().numpy()) < 2e-5, (name, k)
+
+
+def test_short_call_tiles_agree_with_full_tiles():
+    """Calls of up to 8192 points run 32-point tiles in one operand set, longer ones 64-point tiles in two
+    (csrc/mlp.hip, PIR_MLP_HALF).  The arithmetic per point is the same: the first 5000 rows of a 9000-point call
+    (upstream gradient zero on the other rows) must give the outputs and input gradients of the 5000-point call bit
+    for bit; the parameter gradients are sums over rows in another split, so they agree to rounding only."""
+    from pir_amd import scene
+    _, mats, dinonet = scene.build_networks(seed=6, device="cuda")
+    n, N = 5000, 9000
+    pts, nrm, geo, dino = _inputs(N, seed=11)
+    g = torch.Generator().manual_seed(12)
+    for name in NETS:
+        net = mats[name]
+        w = torch.randn(N, 3 if name != "specular_roughness_network" else 1, generator=g).cuda()
+        res = []
+        for rows in (n, N):
+            leaves = [t[:rows].clone().requires_grad_(True) for t in (pts, nrm, geo, dino)]
+            net.zero_grad()
+            out = _call(net, name, *leaves)
+            assert out.shape[1] == w.shape[1]
+            ww = w[:rows].clone()
+            ww[n:] = 0
+            (out * ww).sum().backward()
+            res.append((out.detach()[:n], [None if l.grad is None else l.grad[:n] for l in leaves],
+                        {k: p.grad.clone() for k, p in net.named_parameters()}))
+        (o0, gl0, gp0), (o1, gl1, gp1) = res
+        assert torch.equal(o0, o1), name
+        for a, b, nm in zip(gl0, gl1, ("points", "normals", "geo_f", "dino_f")):
+            assert (a is None) == (b is None), (name, nm)
+            if a is not None:
+                assert torch.equal(a, b), (name, nm)
+        for k in gp0:
+            assert rel_err(gp0[k].cpu().numpy(), gp1[k].cpu().numpy()) < 2e-5, (name, k)
+    with torch.no_grad():
+        assert torch.equal(dinonet(pts[:n], is_training=False), dinonet(pts, is_training=False)[:n])
 
 
 def _graph_has(fn, name):
