@@ -441,6 +441,7 @@ mlp_head_grad_kernel(const float* __restrict__ H, const float* __restrict__ g_ou
   const int col = threadIdx.x;
   const int r0 = (int)((long)blockIdx.x * chunk_n / gridDim.x), r1 = (int)((long)(blockIdx.x + 1) * chunk_n / gridDim.x);
   float s[4] = {0.f, 0.f, 0.f, 0.f}, sg[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8   // rows are independent loads: keep several in flight (a short chunk gives a block ~64 rows)
   for (int r = r0; r < r1; ++r) {
     const float a = H[(size_t)r * 256 + col];
 #pragma unroll
@@ -457,20 +458,21 @@ mlp_head_grad_kernel(const float* __restrict__ H, const float* __restrict__ g_ou
   }
 }
 __global__ void __launch_bounds__(256)
-mlp_head_reduce_kernel(const float* __restrict__ partial, int n_out, float* __restrict__ gw, float* __restrict__ gb) {
+mlp_head_reduce_kernel(const float* __restrict__ partial, int nblocks /* multiple of 8 */, int n_out,
+                       float* __restrict__ gw, float* __restrict__ gb) {
   const int o = blockIdx.x, col = threadIdx.x;
   if (o >= n_out) return;
   // eight interleaved partial sums in a fixed order: the kernel runs on n_out <= 4 workgroups, so it is bound by the
-  // latency of its 512 dependent load-add steps unless several loads are in flight
+  // latency of its dependent load-add steps unless several loads are in flight (and the host keeps nblocks small for
+  // short chunks: 512 partials cost 57 us whatever the chunk)
   float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sg = 0.f;
-  static_assert(kHeadBlocks % 8 == 0, "unrolled by 8");
-  for (int b = 0; b < kHeadBlocks; b += 8) {
+  for (int b = 0; b < nblocks; b += 8) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) s8[u] += partial[((size_t)(b + u) * 4 + o) * 257 + col];
   }
   if (col == 0) {
     float g8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < kHeadBlocks; b += 8) {
+    for (int b = 0; b < nblocks; b += 8) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) g8[u] += partial[((size_t)(b + u) * 4 + o) * 257 + 256];
     }
@@ -481,7 +483,14 @@ mlp_head_reduce_kernel(const float* __restrict__ partial, int n_out, float* __re
   if (col == 0 && gb) gb[o] += sg;
 }
 
-// one 32-point tile per CU covers the call: short-call mode
+// partial-sum blocks of the head gradient for a chunk of n rows: about 64 rows per block, a multiple of 8, at most
+// kHeadBlocks (blocks without rows write zeros)
+static int head_blocks(int n) {
+  static_assert(kHeadBlocks % 8 == 0, "the reduction is unrolled by 8");
+  const int b = ((n + 63) / 64 + 7) / 8 * 8;
+  return b < 8 ? 8 : (b > kHeadBlocks ? kHeadBlocks : b);
+}
+
 static bool mlp_half(long n) { return PIR_MLP_HALF && (n + 31) / 32 <= (long)pir_num_cus(); }
 
 static bool plan_ok(const MlpPlan& pl) {
@@ -630,10 +639,11 @@ int pir_mlp_backward(const void* packed, size_t mats_floats, const PirMlpPlan* p
     if (rc == PIR_OK) rc = flush();
     if (rc != PIR_OK) return rc;
     if (pl.n_out <= 4) {
-      hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(kHeadBlocks), dim3(256), 0, stream, sc.H + (size_t)(L - 1) * sc.stride,
+      const int hb = head_blocks(n);
+      hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(hb), dim3(256), 0, stream, sc.H + (size_t)(L - 1) * sc.stride,
                          g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
-      hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
-                         out.b[L]);
+      hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, hb, pl.n_out,
+                         out.w[L], out.b[L]);
       rc = pir_check_launch();
       if (rc != PIR_OK) return rc;
     }
@@ -724,10 +734,11 @@ int pir_mlp_backward_tangent(const void* packed, size_t mats_floats, const PirMl
     }
     if (rc == PIR_OK) rc = flush();
     if (rc != PIR_OK) return rc;
-    hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(kHeadBlocks), dim3(256), 0, stream, Tn + (size_t)(L - 1) * sc.stride,
+    const int hb = head_blocks(n);
+    hipLaunchKernelGGL(mlp_head_grad_kernel, dim3(hb), dim3(256), 0, stream, Tn + (size_t)(L - 1) * sc.stride,
                        g_out + (size_t)base * pl.n_out, pl.n_out, n, head_partial);
-    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, pl.n_out, out.w[L],
-                       (float*)nullptr);
+    hipLaunchKernelGGL(mlp_head_reduce_kernel, dim3(pl.n_out), dim3(256), 0, stream, head_partial, hb, pl.n_out,
+                       out.w[L], (float*)nullptr);
     rc = pir_check_launch();
     if (rc != PIR_OK) return rc;
   }
