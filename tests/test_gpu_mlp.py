@@ -263,6 +263,44 @@ def test_fused_material_networks_match_reference_fixture():
             assert rel_err(g if g.shape == ref.shape else g[::16], ref) < 4e-5, (name, k)
 
 
+def test_backward_in_small_chunks_matches_one_chunk(monkeypatch):
+    """pir_mlp_backward walks the points in chunks that fit its scratch.  With scratch for 128 rows, 300 points are
+    three chunks (128, 128, 44: every one a short call of 32-point tiles): same input gradients bit for bit as the
+    one-chunk call, parameter gradients (accumulated chunk after chunk) to rounding."""
+    from pir_amd import scene, mlp_hip, sdf_hip
+    _, mats, _ = scene.build_networks(seed=8, device="cuda")
+    name = "specular_albedo_network"
+    net = mats[name]
+    pts, nrm, geo, dino = _inputs(300, seed=13)
+    w = torch.randn(300, 3, generator=torch.Generator().manual_seed(14)).cuda()
+    res = []
+    for chunk in (None, 128):
+        mlp_hip.free_scratch()
+        sdf_hip.free_scratch()
+        if chunk:
+            monkeypatch.setattr(mlp_hip, "BWD_CHUNK_POINTS", chunk)
+        leaves = [t.clone().requires_grad_(True) for t in (pts, nrm, geo, dino)]
+        net.zero_grad()
+        (_call(net, name, *leaves) * w).sum().backward()
+        if chunk:
+            assert mlp_hip._backward_scratch(pts.device, 4, 300).numel() \
+                < _scratch_bytes_for(mlp_hip, 4, 256), "the small scratch was not used"
+        res.append(([l.grad for l in leaves], {k: p.grad.clone() for k, p in net.named_parameters()}))
+    mlp_hip.free_scratch()
+    (gl0, gp0), (gl1, gp1) = res
+    for a, b, nm in zip(gl0, gl1, ("points", "normals", "geo_f", "dino_f")):
+        assert (a is None) == (b is None), nm
+        if a is not None:
+            assert torch.equal(a, b), nm
+    for k in gp0:
+        assert rel_err(gp1[k].cpu().numpy(), gp0[k].cpu().numpy()) < 2e-5, k
+
+
+def _scratch_bytes_for(mlp_hip, n_hidden, rows):
+    from pir_amd import _lib
+    return _lib.lib().pir_mlp_backward_scratch_bytes(n_hidden, rows)
+
+
 def test_mlp_entry_points_reject_bad_arguments():
     """C-ABI error behaviour: malformed plans, missing pointers, scratch too small; P = 0 is accepted and does nothing."""
     import ctypes
