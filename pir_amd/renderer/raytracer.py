@@ -606,7 +606,11 @@ def render_light_visibility(results, camera, light_pos, sdf_network, inv_s, n_sa
     idx = mask_indices(mask)                 # one nonzero (one host sync) for the gather and the scatter
     if idx.numel() > 0:
         pts = results["points"].reshape(-1, 3).index_select(0, idx)
-        v = light_visibility(light_pos, pts, sdf_network, inv_s, n_samples=n_samples, is_training=is_training)
+        if pts.is_cuda:      # the HIP march walks the points in chunks sized to its own scratch
+            v = light_visibility(light_pos, pts, sdf_network, inv_s, n_samples=n_samples, is_training=is_training)
+        else:                # eager expressions: max_num_pts points at a time, as the reference (raytracer.py:745-760)
+            v = torch.cat([light_visibility(light_pos, p, sdf_network, inv_s, n_samples=n_samples, is_training=is_training)
+                           for p in torch.split(pts, max(1, int(max_num_pts)), dim=0)], dim=0)
         with torch.set_grad_enabled(is_training):
             vis = vis.index_put((idx,), v)
     results.update({"vis": vis.reshape(dots_sh)})
