@@ -329,6 +329,24 @@ def test_image_losses_match_reference():
         assert rel_err(pred.grad, d[tag + ".grad"]) < 1e-5, tag
 
 
+def test_ssim_loss_over_an_empty_eroded_mask_is_nan_with_finite_gradients():
+    """The reference's masked SSIM is the mean over the pixels whose whole 11 x 11 window lies in the mask
+    (image_losses.py:150-158).  A crop that touches the object with a few pixels leaves none: the mean of an empty
+    selection is NaN, nothing flows back through it, and the other loss terms keep their finite gradients -- the
+    training loop goes on (seen on ~4 % of the 64 x 64 crops of a soak run).  The port keeps that behaviour."""
+    from pir_amd.models.image_losses import ssim_loss_fn
+    g = torch.Generator().manual_seed(0)
+    pred = torch.rand(1, 3, 32, 32, generator=g).requires_grad_(True)
+    gt = torch.rand(1, 3, 32, 32, generator=g)
+    mask = torch.zeros(1, 1, 32, 32, dtype=torch.bool)
+    mask[..., 10:15, 10:15] = True                       # 5 x 5: no 11 x 11 window fits
+    ssim = ssim_loss_fn(pred, gt, mask)
+    assert torch.isnan(ssim)
+    loss = torch.abs(pred - gt).mean() + ssim            # as render_surface.py:650-653
+    loss.backward()
+    assert torch.isnan(loss) and bool(torch.isfinite(pred.grad).all()) and float(pred.grad.abs().max()) > 0
+
+
 def test_training_step_matches_reference_on_cpu(tmp_path):
     """One stage-2 iteration (render_surface.py:545-699 executed from the reference's text by tools/gen_golden.py):
     view/crop choice, every loss term, every gradient, the optimizer schedule; then the checkpoint round trip."""
