@@ -18,7 +18,7 @@ import json
 import statistics
 import sys
 
-KERNELS = {"sdf_eval_kernel<2>": "sdf_eval_kernel(get_all)", "pir::bwd_sweep_kernel": "bwd_sweep_kernel",
+KERNELS = {"sdf_eval_kernel<2": "sdf_eval_kernel(get_all)", "pir::bwd_sweep_kernel": "bwd_sweep_kernel",
            "pir::wgrad256_kernel": "wgrad256_kernel"}
 # v_mfma_f32_32x32x2_f32: 4096 FLOP and 64 busy cycles on one SIMD per instruction
 FLOP_PER_BUSY_CYCLE = 4096.0 / 64.0

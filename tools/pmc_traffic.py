@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-NAMES = {"sdf_eval_kernel<2>": "sdf_eval_kernel(get_all)", "sdf_eval_kernel<0>": "sdf_eval_kernel(forward)",
+NAMES = {"sdf_eval_kernel<2": "sdf_eval_kernel(get_all)", "sdf_eval_kernel<0": "sdf_eval_kernel(forward)",
          "pir::bwd_sweep_kernel": "bwd_sweep_kernel", "wgrad_kernel": "wgrad_kernel", "wgrad256_kernel": "wgrad256_kernel",
          "mlp_eval_kernel": "mlp_eval_kernel", "mlp_bwd_sweep_kernel": "mlp_bwd_sweep_kernel"}
 SUFFIX = os.environ.get("PMC_SUFFIX", "")     # e.g. "(diffuse)": one entry per profiled network
