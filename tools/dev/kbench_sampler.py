@@ -31,4 +31,5 @@ for P in (64, 128, 256):
     n = reps * len(cams)
     hits = sum(int(raytrace_camera(c, st.sdf_network, st.raytracer)["convergent_mask"].sum()) for c in cams) / len(cams)
     print(f"patch {P}: " + ", ".join(f"{nm} {ms[k] / n:.3f} ms" for k, nm in ((2, "trace_step x17"), (3, "sampler"), (4, "bisect")))
-          + f"  mean hits {hits:.0f}", flush=True)
+          + f"  mean hits {hits:.0f}  evals per trace: trace_step {un[2] / n:.0f}, sampler {un[3] / n:.0f}, bisect {un[4] / n:.0f}"
+          + f"  -> sampler {un[3] * 918016 / (ms[3] * 1e-3) / 1e12:.1f} TFLOP/s", flush=True)
